@@ -1,0 +1,156 @@
+"""GPU parity of the first kernel families against the CPU oracle (through the C ABI)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import frl_oracle as O  # noqa: E402
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    return torch.device("cuda:0")
+
+
+def test_library_reports_gfx950():
+    import ctypes
+    from frl_hip import _lib
+    lib = _lib.load()
+    _dev()
+    buf = ctypes.create_string_buffer(128)
+    _lib.check(lib.frl_device_arch(buf, 128))
+    assert buf.value.decode().startswith("gfx950"), buf.value
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("P,cin,cout", [(1024, 64, 128), (1000, 128, 64), (37, 64, 12), (256, 12, 128),
+                                        (64, 8, 16), (2048, 64, 256), (130, 32, 12), (512, 64, 32)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_conv1x1_fwd(dtype, tol, P, cin, cout, act):
+    from frl_hip import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(P + cin + cout)
+    x = torch.randn(P, cin, generator=g)
+    w = torch.randn(cout, cin, generator=g) / cin ** 0.5
+    b = torch.randn(cout, generator=g)
+    xd = x.to(dtype)
+    wr = w.to(dtype).double() if dtype == torch.bfloat16 else w.double()
+    ref = xd.double() @ wr.t() + b.double()
+    ref = torch.relu(ref) if act == 1 else torch.sigmoid(ref) if act == 2 else ref
+    y = ops.conv1x1_fwd(xd.to(dev), w.to(dev), b.to(dev), act).float().cpu()
+    scale = ref.abs().max().item()
+    assert (y.double() - ref).abs().max().item() <= tol * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("P,cin,cout", [(1024, 64, 128), (1000, 128, 64), (37, 64, 12), (256, 12, 128), (2048, 64, 256)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_conv1x1_bwd(dtype, tol, P, cin, cout, act):
+    from frl_hip import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(P * 3 + cin + cout)
+    x = torch.randn(P, cin, generator=g).to(dtype)
+    w = torch.randn(cout, cin, generator=g) / cin ** 0.5
+    dy = torch.randn(P, cout, generator=g).to(dtype)
+    y = torch.randn(P, cout, generator=g).to(dtype)  # stand-in activation output for the relu mask
+    dyd = dy.double() * ((y.double() > 0).double() if act == 1 else 1.0)
+    wr = w.to(dtype).double() if dtype == torch.bfloat16 else w.double()
+    ref_dx = dyd @ wr
+    ref_dw = dyd.t() @ x.double()
+    ref_db = dyd.sum(0)
+    yd = y.to(dev) if act else None
+    dx = ops.conv1x1_bwd_data(dy.to(dev), w.to(dev), yd, act).float().cpu()
+    assert (dx.double() - ref_dx).abs().max().item() <= tol * max(ref_dx.abs().max().item(), 1.0)
+    for scalar in (False, True):
+        dw, db = ops.conv1x1_bwd_weight(dy.to(dev), x.to(dev), yd, act, scalar_frags=scalar)
+        wtol = 2e-5 if dtype == torch.float32 else 2e-5  # inputs exact in both modes, f32 accumulation over P
+        assert (dw.cpu().double() - ref_dw).abs().max().item() <= wtol * max(ref_dw.abs().max().item(), 1.0) * 4
+        assert (db.cpu().double() - ref_db).abs().max().item() <= wtol * max(ref_db.abs().max().item(), 1.0) * 4
+
+
+def _vq_case(N, K, d, dtype, seed, ties=False):
+    g = torch.Generator().manual_seed(seed)
+    z = torch.randn(N, d, generator=g)
+    e = torch.randn(K, d, generator=g)
+    if ties and K > 8 and N > 8:
+        e[K - 1] = e[3]
+        z[5] = 0.0
+        e[7] = -e[2]
+        z[6] = e[4]  # exact hit
+    zt, et = z.to(dtype), e
+    e_eff = e.to(dtype).float() if dtype == torch.bfloat16 else e
+    idx = torch.from_numpy(O.vq_argmin_np(zt.float().numpy(), e_eff.numpy()))
+    return zt, et, e_eff, idx
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,K,d,ties", [(4096, 256, 64, True), (1000, 16, 8, True), (8192, 512, 64, False),
+                                        (2048, 1024, 64, False), (2048, 640, 128, False), (777, 100, 12, True),
+                                        (64, 16, 4, False)])
+def test_vq_assign_bit_exact(dtype, N, K, d, ties):
+    from frl_hip import ops
+    dev = _dev()
+    zt, et, e_eff, idx_ref = _vq_case(N, K, d, dtype, seed=N + K + d, ties=ties)
+    idx, zq, stats, counts = ops.vq_assign(zt.to(dev), et.to(dev))
+    idx = idx.cpu().long()
+    assert torch.equal(idx, idx_ref), f"{(idx != idx_ref).sum().item()} mismatching indices"
+    zq_ref = e_eff[idx_ref].to(dtype)
+    assert torch.equal(zq.cpu(), zq_ref)
+    sq_ref = ((zt.double() - zq_ref.double()) ** 2).sum().item()
+    assert abs(stats[0].item() - sq_ref) <= 1e-5 * sq_ref
+    cnt_ref = torch.bincount(idx_ref, minlength=K)
+    assert torch.equal(counts.cpu().long(), cnt_ref)
+    p = cnt_ref.double() / N
+    perp = torch.exp(-(p * torch.log(p + 1e-10)).sum()).item()
+    assert abs(stats[1].item() - perp) <= 1e-4 * perp
+    assert stats[2].item() < 0.05 * N + 8  # few rows needed the float64 path
+
+
+def test_vq_golden_fixture(golden_dir):
+    from frl_hip import ops
+    dev = _dev()
+    fx = np.load(f"{golden_dir}/vq_seed7.npz")
+    z, e = torch.from_numpy(fx["z"]), torch.from_numpy(fx["e"])
+    idx, zq, stats, counts = ops.vq_assign(z.to(dev), e.to(dev))
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), fx["idx"])
+    n, d = z.shape
+    mse = stats[0].item() / (n * d)
+    assert abs(mse * 1.25 - float(fx["vq_loss"])) <= 1e-5 * float(fx["vq_loss"])
+    assert abs(stats[1].item() - float(fx["perplexity"])) <= 1e-4 * float(fx["perplexity"])
+    # backward: g_z, g_E
+    gout = torch.from_numpy(fx["gout"]).float()
+    gz, ge, sums = ops.vq_bwd(gout.to(dev), z.to(dev), e.to(dev), idx, counts, None, 0.25, want_sums=True)
+    assert np.abs(gz.cpu().numpy() - fx["grad_z"]).max() <= 1e-5 * max(1.0, np.abs(fx["grad_z"]).max())
+    assert np.abs(ge.cpu().numpy() - fx["grad_e"]).max() <= 1e-5 * max(1e-3, np.abs(fx["grad_e"]).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vq_bwd_and_ema(dtype):
+    from frl_hip import ops
+    dev = _dev()
+    N, K, d = 3000, 96, 64
+    zt, et, e_eff, idx_ref = _vq_case(N, K, d, dtype, seed=3)
+    g = torch.Generator().manual_seed(9)
+    gout = torch.randn(N, d, generator=g).to(dtype)
+    idx, zq, stats, counts = ops.vq_assign(zt.to(dev), et.to(dev))
+    gs = torch.tensor([0.7], device=dev)
+    gz, ge, sums = ops.vq_bwd(gout.to(dev), zt.to(dev), et.to(dev), idx, counts, gs, 0.25, want_sums=True)
+    zq_ref = e_eff[idx_ref].double()
+    gz_ref = gout.double() + 0.7 * 0.25 * 2 / (N * d) * (zt.double() - zq_ref)
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert (gz.float().cpu().double() - gz_ref).abs().max().item() <= tol * gz_ref.abs().max().item()
+    sums_ref = torch.zeros(K, d, dtype=torch.float64).index_add_(0, idx_ref, zt.double())
+    cnt = torch.bincount(idx_ref, minlength=K).double()
+    ge_ref = 0.7 * 2 / (N * d) * (cnt[:, None] * e_eff.double() - sums_ref)
+    assert (sums.cpu().double() - sums_ref).abs().max().item() <= 1e-5 * sums_ref.abs().max().item()
+    assert (ge.cpu().double() - ge_ref).abs().max().item() <= 1e-4 * ge_ref.abs().max().item()
+    # EMA
+    ema_c = torch.rand(K, generator=g) * 10
+    ema_s = torch.randn(K, d, generator=g)
+    cb_ref, c_ref, s_ref = O.vq_ema_update(et.double(), ema_c.double(), ema_s.double(), zt.double(), idx_ref, 0.99, 1e-5)
+    cb, ec, es = et.clone().to(dev), ema_c.to(dev), ema_s.to(dev)
+    ops.vq_ema_update(sums, counts, ec, es, cb, 0.99, 1e-5)
+    assert (ec.cpu().double() - c_ref).abs().max().item() <= 1e-5 * c_ref.abs().max().item()
+    assert (es.cpu().double() - s_ref).abs().max().item() <= 1e-5 * s_ref.abs().max().item()
+    assert (cb.cpu().double() - cb_ref).abs().max().item() <= 1e-4 * cb_ref.abs().max().item()

@@ -1,0 +1,280 @@
+// Weight gradient of pointwise / temporal-tap convolutions:
+//   dW[oc][ic] = sum_p (dY .* act'(Y))[p][oc] * X[p + shift][ic],   db[oc] = sum_p (dY .* act'(Y))[p][oc]
+// GEMM with K = pixels: A = dY^T, B = X, both k-strided in NHWC memory, so 64-pixel tiles are staged
+// row-major in LDS and the k-strided MFMA fragments are fetched with the gfx950 transposing read
+// ds_read_b64_tr_b16 (bf16) or plain ds_read_b32 (f32, 16x16x4 takes one f32 per lane).
+// Each workgroup reduces a contiguous pixel range into a private f32 slab; a second kernel sums the
+// slabs in a fixed order (bit-reproducible, no float atomics).
+// Replaces autograd's conv weight-gradient for: conv2d_encoder.py:106-114, spatial.py:262-263,
+// tcn.py:56-69 (3 temporal taps = 3 shifted calls), conditioning.py:55-67, representation.py:169, decoders.
+#include "frl_common.hpp"
+#include "frl_host.hpp"
+
+#define WG_KP 64
+
+template <typename T, int OBW, int IB>
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(
+    const T* __restrict__ dY, const T* __restrict__ Ymask, int mask_act, const T* __restrict__ X,
+    float* __restrict__ slab, int64_t P, int Cout, int Cin, int64_t rows_per_wg, int HW, int Tn, int toff,
+    int use_tr) {
+  typedef typename DT<T>::frag_t frag_t;
+  constexpr int FE = DT<T>::FE;
+  constexpr int VEC = DT<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int CoP = OBW * 4 * 16, CiP = IB * 16;
+  const int pitchA = CoP + 8, pitchB = CiP + 8;      // elements; keeps 16-B row alignment, skews banks
+  T* ldsA = reinterpret_cast<T*>(smem);
+  T* ldsB = ldsA + WG_KP * pitchA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kc = lane >> 4;
+
+  f32x4 acc[OBW][IB];
+#pragma unroll
+  for (int o = 0; o < OBW; ++o)
+#pragma unroll
+    for (int i = 0; i < IB; ++i) acc[o][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  const int64_t p_begin = (int64_t)blockIdx.x * rows_per_wg;
+  int64_t p_end = p_begin + rows_per_wg;
+  if (p_end > P) p_end = P;
+  const bool fastA = (Cout % VEC) == 0, fastB = (Cin % VEC) == 0;
+  const int64_t shift = (int64_t)toff * HW;
+
+  for (int64_t p0 = p_begin; p0 < p_end; p0 += WG_KP) {
+    __syncthreads();
+    // ---- stage dY tile (with activation-derivative mask) ----
+    {
+      const int vpr = CoP / VEC;                         // vectors per row
+      for (int i = tid; i < WG_KP * vpr; i += 256) {
+        const int row = i / vpr, c0 = (i % vpr) * VEC;
+        const int64_t p = p0 + row;
+        float v[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = 0.f;
+        if (p < p_end && c0 < Cout) {
+          const T* src = dY + p * (int64_t)Cout + c0;
+          if (fastA) {
+            Vec<T>::load(src, v);
+            if (Ymask != nullptr) {
+              float m[VEC];
+              Vec<T>::load(Ymask + p * (int64_t)Cout + c0, m);
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) v[e] *= act_bwd_from_y(m[e], mask_act);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+              if (c0 + e < Cout) {
+                v[e] = to_f32(src[e]);
+                if (Ymask != nullptr) v[e] *= act_bwd_from_y(to_f32(Ymask[p * (int64_t)Cout + c0 + e]), mask_act);
+              }
+          }
+        }
+        Vec<T>::store(ldsA + row * pitchA + c0, v);
+      }
+      // ---- stage X tile (row-shifted, zero outside the valid time range) ----
+      const int vprb = CiP / VEC;
+      for (int i = tid; i < WG_KP * vprb; i += 256) {
+        const int row = i / vprb, c0 = (i % vprb) * VEC;
+        const int64_t p = p0 + row;
+        float v[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = 0.f;
+        bool ok = p < p_end && c0 < Cin;
+        if (ok && Tn > 1) {
+          const int t = (int)((p / HW) % Tn) + toff;
+          ok = (t >= 0 && t < Tn);
+        }
+        if (ok) {
+          const T* src = X + (p + shift) * (int64_t)Cin + c0;
+          if (fastB) Vec<T>::load(src, v);
+          else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+              if (c0 + e < Cin) v[e] = to_f32(src[e]);
+          }
+        }
+        Vec<T>::store(ldsB + row * pitchB + c0, v);
+      }
+    }
+    __syncthreads();
+    // ---- bias gradient: column sums of the staged dY tile ----
+    if (tid < Cout) {
+      float s = 0.f;
+      for (int row = 0; row < WG_KP; ++row) s += to_f32(ldsA[row * pitchA + tid]);
+      bsum += s;
+    }
+    // ---- MFMA over the tile's pixels ----
+    if constexpr (FE == 8) {
+#pragma unroll
+      for (int ks = 0; ks < WG_KP / 32; ++ks) {
+        const int pix0 = ks * 32 + 8 * kc;
+        bf16x8 bf[IB];
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+          const int ch0 = i * 16;
+          if (use_tr) {
+            // lane i16 of the 16-lane group supplies row (i16>>2), columns 4*(i16&3)..+3 and receives column i16
+            const T* a0 = ldsB + (pix0 + (r16 >> 2)) * pitchB + ch0 + 4 * (r16 & 3);
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (bf16x4 __attribute__((address_space(3)))*)(a0));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (bf16x4 __attribute__((address_space(3)))*)(a0 + 4 * pitchB));
+            bf[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bf[i][j] = ldsB[(pix0 + j) * pitchB + ch0 + r16];
+          }
+        }
+#pragma unroll
+        for (int o = 0; o < OBW; ++o) {
+          const int ch0 = (wave * OBW + o) * 16;
+          bf16x8 af;
+          if (use_tr) {
+            const T* a0 = ldsA + (pix0 + (r16 >> 2)) * pitchA + ch0 + 4 * (r16 & 3);
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (bf16x4 __attribute__((address_space(3)))*)(a0));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (bf16x4 __attribute__((address_space(3)))*)(a0 + 4 * pitchA));
+            af = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) af[j] = ldsA[(pix0 + j) * pitchA + ch0 + r16];
+          }
+#pragma unroll
+          for (int i = 0; i < IB; ++i) acc[o][i] = mfma16(af, bf[i], acc[o][i]);
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int ks = 0; ks < WG_KP / 4; ++ks) {
+        const int pix = ks * 4 + kc;
+        float bf[IB];
+#pragma unroll
+        for (int i = 0; i < IB; ++i) bf[i] = ldsB[pix * pitchB + i * 16 + r16];
+#pragma unroll
+        for (int o = 0; o < OBW; ++o) {
+          const float af = ldsA[pix * pitchA + (wave * OBW + o) * 16 + r16];
+#pragma unroll
+          for (int i = 0; i < IB; ++i) acc[o][i] = mfma16(af, bf[i], acc[o][i]);
+        }
+      }
+    }
+  }
+  // ---- write the private slab: [Cout*Cin] weights then [Cout] bias ----
+  float* my = slab + (int64_t)blockIdx.x * ((int64_t)Cout * Cin + Cout);
+#pragma unroll
+  for (int o = 0; o < OBW; ++o)
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int oc = (wave * OBW + o) * 16 + kc * 4 + r, ic = i * 16 + r16;
+        if (oc < Cout && ic < Cin) my[(int64_t)oc * Cin + ic] = acc[o][i][r];
+      }
+  if (tid < Cout) my[(int64_t)Cout * Cin + tid] = bsum;
+}
+
+// out[i] (+)= sum over slabs, fixed order.  dw strides let the caller scatter a tap slice of a
+// [Cout][Cin][ntap] tensor: dst = dW[oc * dso + ic * dsi].
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nslab, int Cout, int Cin, float* dW,
+                                   int64_t dso, int64_t dsi, float* dB, int accumulate_bias) {
+  const int64_t n = (int64_t)Cout * Cin + Cout;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nslab; ++k) s += slab[(int64_t)k * n + i];
+  if (i < (int64_t)Cout * Cin) {
+    const int oc = (int)(i / Cin), ic = (int)(i % Cin);
+    dW[oc * dso + ic * dsi] = s;
+  } else if (dB != nullptr) {
+    const int oc = (int)(i - (int64_t)Cout * Cin);
+    if (accumulate_bias) dB[oc] += s; else dB[oc] = s;
+  }
+}
+
+static int wgrad_nwg(int64_t P) {
+  int64_t n = (P + WG_KP - 1) / WG_KP;
+  if (n > 512) n = 512;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
+template <typename T, int OBW, int IB>
+static int launch_wgrad(const void* dy, const void* ymask, int mask_act, const void* x, float* ws, int64_t P,
+                        int Cout, int Cin, int HW, int Tn, int toff, int use_tr, hipStream_t st) {
+  const int nwg = wgrad_nwg(P);
+  int64_t rows = (P + nwg - 1) / nwg;
+  rows = (rows + WG_KP - 1) / WG_KP * WG_KP;
+  const size_t lds = (size_t)WG_KP * ((OBW * 64 + 8) + (IB * 16 + 8)) * sizeof(T);
+  auto kern = pw_wgrad_kernel<T, OBW, IB>;
+  if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, (const T*)dy, (const T*)ymask, mask_act, (const T*)x, ws,
+                     P, Cout, Cin, rows, HW, Tn, toff, use_tr);
+  return frl_check_launch("pw_wgrad");
+}
+
+template <typename T>
+static int dispatch_wgrad(const void* dy, const void* ymask, int mask_act, const void* x, float* ws, int64_t P,
+                          int Cout, int Cin, int HW, int Tn, int toff, int use_tr, hipStream_t st) {
+  const int ob = (Cout + 63) / 64;   // oc blocks per wave (4 waves x 16 rows)
+  const int ib = (Cin + 15) / 16;
+#define WG_CASE(O, I) return launch_wgrad<T, O, I>(dy, ymask, mask_act, x, ws, P, Cout, Cin, HW, Tn, toff, use_tr, st)
+  if (ob <= 1) {
+    if (ib <= 1) WG_CASE(1, 1);
+    if (ib <= 2) WG_CASE(1, 2);
+    if (ib <= 4) WG_CASE(1, 4);
+    if (ib <= 8) WG_CASE(1, 8);
+    if (ib <= 16) WG_CASE(1, 16);
+  } else if (ob <= 2) {
+    if (ib <= 1) WG_CASE(2, 1);
+    if (ib <= 2) WG_CASE(2, 2);
+    if (ib <= 4) WG_CASE(2, 4);
+    if (ib <= 8) WG_CASE(2, 8);
+  } else if (ob <= 4) {
+    if (ib <= 1) WG_CASE(4, 1);
+    if (ib <= 2) WG_CASE(4, 2);
+    if (ib <= 4) WG_CASE(4, 4);
+    if (ib <= 8) WG_CASE(4, 8);
+  }
+#undef WG_CASE
+  return frl_fail(-2, "conv1x1_bwd_weight: unsupported (Cout, Cin) combination");
+}
+
+extern "C" {
+
+size_t frl_conv1x1_bwd_weight_workspace_bytes(int64_t P, int Cin, int Cout) {
+  return (size_t)wgrad_nwg(P) * ((size_t)Cout * Cin + Cout) * sizeof(float);
+}
+
+// General form: rows are (b, t, hw) with T time steps; X is read at time t + toff (zero outside [0,T)).
+// dW destination strides (dso, dsi) let one call fill tap `k` of a [Cout][Cin][ntap] tensor.
+// flags: bit0 = use scalar LDS fragment reads instead of ds_read_b64_tr_b16 (debug / A-B check),
+//        bit1 = accumulate into dbias instead of overwriting.
+int frl_conv_tap_bwd_weight(const void* dy, const void* y, int act, const void* x, float* dw, int64_t dso,
+                            int64_t dsi, float* dbias, int64_t P, int Cin, int Cout, int HW, int T, int toff,
+                            int dtype, void* ws, size_t ws_bytes, int flags, hipStream_t stream) {
+  if (P <= 0) return frl_fail(-2, "bwd_weight: empty input");
+  if (ws_bytes < frl_conv1x1_bwd_weight_workspace_bytes(P, Cin, Cout)) return frl_fail(-4, "bwd_weight: workspace too small");
+  if (Cout > 256) return frl_fail(-2, "bwd_weight: Cout > 256 unsupported");
+  const void* ym = act != FRL_ACT_NONE ? y : nullptr;
+  const int use_tr = (flags & 1) ? 0 : 1;
+  int rc;
+  if (dtype == FRL_F32) rc = dispatch_wgrad<float>(dy, ym, act, x, (float*)ws, P, Cout, Cin, HW, T, toff, 0, stream);
+  else if (dtype == FRL_BF16) rc = dispatch_wgrad<bf16>(dy, ym, act, x, (float*)ws, P, Cout, Cin, HW, T, toff, use_tr, stream);
+  else return frl_fail(-2, "bwd_weight: bad dtype");
+  if (rc) return rc;
+  const int64_t n = (int64_t)Cout * Cin + Cout;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)ws,
+                     wgrad_nwg(P), Cout, Cin, dw, dso, dsi, dbias, (flags & 2) ? 1 : 0);
+  return frl_check_launch("slab_reduce");
+}
+
+int frl_conv1x1_bwd_weight(const void* dy, const void* y, int act, const void* x, float* dw, float* dbias,
+                           int64_t P, int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+  return frl_conv_tap_bwd_weight(dy, y, act, x, dw, Cin, 1, dbias, P, Cin, Cout, 1, 1, 0, dtype, ws, ws_bytes, 0,
+                                 stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,568 @@
+// Vector-quantisation step: nearest-codebook assignment, straight-through / commitment gradients,
+// EMA codebook statistics.  The reference no longer ships a quantizer; the definition implemented here
+// is SURVEY.md section 8a row a11 (constants: frl/config/frl_model_v0.yaml:29-35,
+// frl/config/frl_bindings_v0.yaml:887-891, scripts/train_vqvae.py:410-436).
+//
+// vq_assign: for every row z_n find argmin_k ||z_n - e_k||^2 (first index on ties), bit-exact against a
+// float64 evaluation, while running the -2 z.e term on the matrix cores:
+//   * codebook chunk (<= 512 codes) staged once per workgroup in LDS as packed MFMA A fragments holding
+//     -2*e, plus ||e||^2; z streams from HBM as lane-quarter B fragments (16 vectors per tile, 16 B / lane);
+//   * accumulator initialised with ||e_k||^2 + ||z_n||^2 (+ a per-vector positive bias) so that the MFMA
+//     result is the (positive) squared distance;  key = (f32 bits & ~511) | local index, so that ONE
+//     v_min_u32 tracks the running arg-min and ONE v_med3_u32 the runner-up, wave-level min-reduce over
+//     the 4 lane groups by __shfl_xor at the end;
+//   * rows whose runner-up is within the rigorous rounding + truncation bound of the minimum are flagged
+//     (idx = -1 - provisional) and re-evaluated exactly in float64 by vq_fixup (<1 % of rows);
+//   * z_q gather, squared-error partial sums and the per-workgroup code histogram are fused in.
+// Roofline: HBM for K <= 1024 (algorithmic bytes/vector = 2*d*s + 4), MFMA for K = 8192.
+#include "frl_common.hpp"
+#include "frl_host.hpp"
+#include <math.h>
+
+#define VQ_IDX_BITS 9
+#define VQ_IDX_MASK 511u
+#define VQ_MAX_CHUNK 512
+
+struct VqHeader {           // lives at the start of the workspace
+  unsigned enmax_bits;      // max_k ||e_k||^2 as f32 bits (atomicMax on positive floats)
+  unsigned pad[3];
+};
+
+// ---------------------------------------------------------------------------------------------
+// prep: en[k] = ||round_T(e_k)||^2 (f32), enmax
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void vq_prep_kernel(const float* __restrict__ E, int K, int d, float* __restrict__ en, VqHeader* hdr) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f;
+  for (int j = 0; j < d; ++j) {
+    const float v = to_f32(from_f32<T>(E[(int64_t)k * d + j]));
+    s = fmaf(v, v, s);
+  }
+  en[k] = s;
+  atomicMax(&hdr->enmax_bits, __float_as_uint(s));
+}
+
+// ---------------------------------------------------------------------------------------------
+// main assignment kernel
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NF, int NT>
+__global__ __launch_bounds__(256) void vq_assign_kernel(
+    const T* __restrict__ Z, const float* __restrict__ E, const float* __restrict__ en_g, const VqHeader* __restrict__ hdr,
+    int64_t N, int K, int d, int Kc, int32_t* __restrict__ idx_out, T* __restrict__ zq_out,
+    float* __restrict__ partial /*[grid*4]*/, int32_t* __restrict__ hist_slab /*[grid][K]*/) {
+  typedef typename DT<T>::frag_t frag_t;
+  constexpr int FE = DT<T>::FE;
+  constexpr int q = NF * FE;                 // channels per lane quarter
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  frag_t* wl = reinterpret_cast<frag_t*>(smem);                       // [Kc/16][NF][64]
+  float* enl = reinterpret_cast<float*>(smem + (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t));  // [Kc]
+  int* hist = reinterpret_cast<int*>(enl + Kc);                        // [K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vx = lane & 15, kc = lane >> 4;
+  const int nchunks = (K + Kc - 1) / Kc;
+  const bool fast = (d == 4 * q);
+  const float enmax = __uint_as_float(hdr->enmax_bits);
+  const float err_rel = (float)(4 * q + 16) * 1.1920929e-7f;           // (d_pad+16) * 2^-23
+  const float thr_rel = 1.220703125e-4f + 2.f * err_rel;               // 2^-13 + 2*err
+
+  for (int k = tid; k < K; k += 256) hist[k] = 0;
+  float sq_acc = 0.f;
+  int filled_chunk = -1;
+
+  const int64_t vec_per_batch = 4 * NT * 16;
+  const int64_t nbatch = (N + vec_per_batch - 1) / vec_per_batch;
+  for (int64_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+    const int64_t v0 = (batch * 4 + wave) * (NT * 16);
+    LQTile<T, NF> zt[NT];
+    float biasv[NT], thr[NT];
+    unsigned g1[NT], g2[NT];
+    int gc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      int64_t row = v0 + t * 16 + vx;
+      if (row >= N) row = N - 1;
+      lq_load<T, NF>(zt[t], Z, row, d, kc, fast);
+      float zn = 0.f;
+#pragma unroll
+      for (int s = 0; s < NF; ++s)
+#pragma unroll
+        for (int e = 0; e < FE; ++e) { const float v = lq_get<T, NF>(zt[t], s, e); zn = fmaf(v, v, zn); }
+      zn += __shfl_xor(zn, 16, 64);
+      zn += __shfl_xor(zn, 32, 64);
+      const float extra = 9.765625e-4f * (zn + enmax) + 1e-30f;      // 2^-10 (zn + enmax): keeps scores > 0
+      biasv[t] = zn + extra;
+      const float sroot = sqrtf(zn) + sqrtf(enmax);
+      thr[t] = (sroot * sroot + extra) * thr_rel;
+      g1[t] = 0xFFFFFFFFu; g2[t] = 0xFFFFFFFFu; gc[t] = 0;
+    }
+    for (int c = 0; c < nchunks; ++c) {
+      if (filled_chunk != c) {
+        __syncthreads();
+        const int kbase = c * Kc;
+        const int total = (Kc / 16) * NF * 64;
+        for (int i = tid; i < total; i += 256) {
+          const int ln = i & 63, fs = i >> 6;
+          const int s = fs % NF, mb = fs / NF;
+          const int code = kbase + mb * 16 + (ln & 15), kq = ln >> 4;
+          if constexpr (FE == 8) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int ch = q * kq + 8 * s + e;
+              v[e] = (code < K && ch < d) ? (bf16)(-2.f * (float)(bf16)E[(int64_t)code * d + ch]) : (bf16)0.f;
+            }
+            wl[i] = v;
+          } else {
+            const int ch = q * kq + s;
+            wl[i] = (code < K && ch < d) ? -2.f * E[(int64_t)code * d + ch] : 0.f;
+          }
+        }
+        for (int i = tid; i < Kc; i += 256) enl[i] = (kbase + i < K) ? en_g[kbase + i] : 3.0e38f;
+        __syncthreads();
+        filled_chunk = c;
+      }
+      unsigned c1[NT], c2[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { c1[t] = 0xFFFFFFFFu; c2[t] = 0xFFFFFFFFu; }
+      const int nmb = Kc / 16;
+      for (int mb = 0; mb < nmb; ++mb) {
+        const f32x4 en4 = *reinterpret_cast<const f32x4*>(enl + mb * 16 + 4 * kc);
+        frag_t a[NF];
+#pragma unroll
+        for (int s = 0; s < NF; ++s) a[s] = wl[(mb * NF + s) * 64 + lane];
+        const unsigned lidx = (unsigned)(mb * 16 + 4 * kc);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          f32x4 acc = {en4[0] + biasv[t], en4[1] + biasv[t], en4[2] + biasv[t], en4[3] + biasv[t]};
+#pragma unroll
+          for (int s = 0; s < NF; ++s) acc = mfma16(a[s], zt[t].f[s], acc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned key = (__float_as_uint(acc[r]) & ~VQ_IDX_MASK) | (lidx + r);
+            { const unsigned mx = c1[t] > key ? c1[t] : key; c2[t] = c2[t] < mx ? c2[t] : mx; }
+            c1[t] = c1[t] < key ? c1[t] : key;
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const unsigned hi = g1[t] > c1[t] ? g1[t] : c1[t];
+        const unsigned lo2 = g2[t] < c2[t] ? g2[t] : c2[t];
+        g2[t] = hi < lo2 ? hi : lo2;
+        if (c1[t] < g1[t]) { g1[t] = c1[t]; gc[t] = c; }
+      }
+    }
+    // ---- wave-level min-reduce over the 4 lane groups that share a vector ----
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int off = 16; off <= 32; off <<= 1) {
+        const unsigned o1 = __shfl_xor(g1[t], off, 64), o2 = __shfl_xor(g2[t], off, 64);
+        const int oc = __shfl_xor(gc[t], off, 64);
+        const unsigned hi = g1[t] > o1 ? g1[t] : o1;
+        const unsigned lo2 = g2[t] < o2 ? g2[t] : o2;
+        g2[t] = hi < lo2 ? hi : lo2;
+        // deterministic tie rule between lane groups: smaller (key, chunk) wins
+        if (o1 < g1[t] || (o1 == g1[t] && oc < gc[t])) { g1[t] = o1; gc[t] = oc; }
+      }
+      const int64_t row = v0 + t * 16 + vx;
+      const int code = gc[t] * Kc + (int)(g1[t] & VQ_IDX_MASK);
+      const float s1 = __uint_as_float(g1[t] & ~VQ_IDX_MASK), s2 = __uint_as_float(g2[t] & ~VQ_IDX_MASK);
+      const bool amb = !((s2 - s1) > thr[t]);   // also catches NaN
+      if (row < N) {
+        if (kc == 0) idx_out[row] = amb ? (-1 - code) : code;
+        if (!amb) {
+          // gather z_q (rounded to T) for this lane's channel quarter, accumulate squared error
+          const float* er = E + (int64_t)code * d + q * kc;
+          T* zo = zq_out + row * (int64_t)d + q * kc;
+          if (fast) {
+#pragma unroll
+            for (int s = 0; s < NF * FE; s += DT<T>::VEC) {
+              float ev[DT<T>::VEC];
+#pragma unroll
+              for (int e = 0; e < DT<T>::VEC; ++e) ev[e] = to_f32(from_f32<T>(er[s + e]));
+              Vec<T>::store(zo + s, ev);
+#pragma unroll
+              for (int e = 0; e < DT<T>::VEC; ++e) {
+                const float df = lq_get<T, NF>(zt[t], (s + e) / FE, (s + e) % FE) - ev[e];
+                sq_acc = fmaf(df, df, sq_acc);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int s = 0; s < NF * FE; ++s) {
+              if (q * kc + s < d) {
+                const float ev = to_f32(from_f32<T>(er[s]));
+                zo[s] = from_f32<T>(ev);
+                const float df = lq_get<T, NF>(zt[t], s / FE, s % FE) - ev;
+                sq_acc = fmaf(df, df, sq_acc);
+              }
+            }
+          }
+          if (kc == 0) atomicAdd(&hist[code], 1);
+        }
+      }
+    }
+  }
+  // ---- per-workgroup outputs: 4 wave partials of the squared error, histogram slab ----
+  const float ws_ = wave_sum(sq_acc);
+  if (lane == 0) partial[blockIdx.x * 4 + wave] = ws_;
+  __syncthreads();
+  for (int k = tid; k < K; k += 256) hist_slab[(int64_t)blockIdx.x * K + k] = hist[k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact float64 re-evaluation of flagged rows.  Each wave scans a fixed row range (deterministic).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void vq_fixup_kernel(const T* __restrict__ Z, const float* __restrict__ E, int64_t N,
+                                                       int K, int d, int64_t rows_per_wave, int32_t* __restrict__ idx_out,
+                                                       T* __restrict__ zq_out, float* __restrict__ partial_fix,
+                                                       int32_t* __restrict__ counts_fix, int32_t* __restrict__ namb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* zrow = reinterpret_cast<double*>(smem) + (size_t)wave * d;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t r0 = gw * rows_per_wave;
+  int64_t r1 = r0 + rows_per_wave;
+  if (r1 > N) r1 = N;
+  float sq = 0.f;
+  int cnt = 0;
+  for (int64_t base = r0; base < r1; base += 64) {
+    const int64_t myrow = base + lane;
+    const int myidx = (myrow < r1) ? idx_out[myrow] : 0;
+    unsigned long long m = __ballot(myidx < 0);
+    while (m) {
+      const int bit = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int64_t n = base + bit;
+      for (int j = lane; j < d; j += 64) zrow[j] = (double)to_f32(Z[n * (int64_t)d + j]);
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      double best = 1.0e300;
+      int bestk = 0x7fffffff;
+      for (int k = lane; k < K; k += 64) {
+        const float* er = E + (int64_t)k * d;
+        double s = 0.0;
+        for (int j = 0; j < d; ++j) {
+          const double df = zrow[j] - (double)to_f32(from_f32<T>(er[j]));
+          s += df * df;
+        }
+        if (s < best) { best = s; bestk = k; }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off, 64);
+        const int ok = __shfl_xor(bestk, off, 64);
+        if (ob < best || (ob == best && ok < bestk)) { best = ob; bestk = ok; }
+      }
+      for (int j = lane; j < d; j += 64) {
+        const float ev = to_f32(from_f32<T>(E[(int64_t)bestk * d + j]));
+        zq_out[n * (int64_t)d + j] = from_f32<T>(ev);
+        const float df = (float)zrow[j] - ev;
+        sq = fmaf(df, df, sq);
+      }
+      if (lane == 0) { idx_out[n] = bestk; atomicAdd(&counts_fix[bestk], 1); }
+      ++cnt;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  const float s = wave_sum(sq);
+  if (lane == 0) { partial_fix[gw] = s; if (cnt) atomicAdd(namb, cnt); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize: counts[k] = sum_wg hist + fix ; stats = {sqerr_sum, perplexity, n_ambiguous, 0}
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restrict__ partial, int npartial,
+                                                          const int32_t* __restrict__ hist_slab, int nslab, int K,
+                                                          const int32_t* __restrict__ counts_fix, const int32_t* namb,
+                                                          int64_t N, int32_t* __restrict__ counts_out, float* __restrict__ stats) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < npartial; i += 256) s += (double)partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  const double sq = red[0];
+  __syncthreads();
+  double h = 0.0;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    int c = counts_fix[k];
+    for (int w = 0; w < nslab; ++w) c += hist_slab[(int64_t)w * K + k];
+    counts_out[k] = c;
+    const double p = (double)c / (double)N;
+    h += p * log(p + 1e-10);
+  }
+  red[threadIdx.x] = h;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) {
+    stats[0] = (float)sq;
+    stats[1] = (float)exp(-red[0]);
+    stats[2] = (float)(*namb);
+    stats[3] = 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward: g_z = g_out + cz * (z - e_idx) ; code sums S_k = sum_{n: idx=k} z_n (LDS f32 accumulation)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void vq_bwd_kernel(const T* __restrict__ gout, const T* __restrict__ Z,
+                                                     const float* __restrict__ E, const int32_t* __restrict__ idx,
+                                                     const float* __restrict__ gscale, float cz_base, int64_t N, int K, int d,
+                                                     int Kc, int64_t rows_per_wg, T* __restrict__ gz,
+                                                     float* __restrict__ slab /*[grid][K][d]*/) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* acc = reinterpret_cast<float*>(smem);        // [Kc][d]
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  int64_t r1 = r0 + rows_per_wg;
+  if (r1 > N) r1 = N;
+  const float cz = cz_base * (gscale ? gscale[0] : 1.f);
+  constexpr int VEC = DT<T>::VEC;
+  const bool fast = (d % VEC) == 0;
+  const int vpr = (d + VEC - 1) / VEC;                // vectors per row
+  const int nchunks = (K + Kc - 1) / Kc;
+  for (int c = 0; c < nchunks; ++c) {
+    const int kbase = c * Kc;
+    __syncthreads();
+    for (int i = tid; i < Kc * d; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    const int64_t nvec = (r1 > r0 ? (r1 - r0) : 0) * vpr;
+    for (int64_t i = tid; i < nvec; i += 256) {
+      const int64_t n = r0 + i / vpr;
+      const int c0 = (int)(i % vpr) * VEC;
+      const int k = idx[n];
+      const bool mine = (k >= kbase && k < kbase + Kc);
+      if (c == 0 || mine) {
+        float zv[VEC];
+        if (fast) Vec<T>::load(Z + n * (int64_t)d + c0, zv);
+        else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) zv[e] = (c0 + e < d) ? to_f32(Z[n * (int64_t)d + c0 + e]) : 0.f;
+        }
+        if (mine) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            if (c0 + e < d) atomicAdd(&acc[(k - kbase) * d + c0 + e], zv[e]);
+        }
+        if (c == 0 && gz != nullptr) {
+          float gv[VEC], ov[VEC];
+          if (gout != nullptr) {
+            if (fast) Vec<T>::load(gout + n * (int64_t)d + c0, gv);
+            else {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) gv[e] = (c0 + e < d) ? to_f32(gout[n * (int64_t)d + c0 + e]) : 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) gv[e] = 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float ev = (c0 + e < d) ? to_f32(from_f32<T>(E[(int64_t)k * d + c0 + e])) : 0.f;
+            ov[e] = gv[e] + cz * (zv[e] - ev);
+          }
+          if (fast) Vec<T>::store(gz + n * (int64_t)d + c0, ov);
+          else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+              if (c0 + e < d) gz[n * (int64_t)d + c0 + e] = from_f32<T>(ov[e]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int kn = (K - kbase) < Kc ? (K - kbase) : Kc;
+    float* dst = slab + ((int64_t)blockIdx.x * K + kbase) * d;
+    for (int i = tid; i < kn * d; i += 256) dst[i] = acc[i];
+  }
+}
+
+// g_E[k][j] = ce * gscale * (n_k * e_k[j] - sum_wg slab[wg][k][j]);  also exports code sums when asked
+template <typename T>
+__global__ void vq_code_reduce_kernel(const float* __restrict__ slab, int nslab, const float* __restrict__ E,
+                                      const int32_t* __restrict__ counts, const float* __restrict__ gscale, float ce_base,
+                                      int K, int d, float* __restrict__ gE, float* __restrict__ sums_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)K * d) return;
+  float s = 0.f;
+  for (int w = 0; w < nslab; ++w) s += slab[(int64_t)w * K * d + i];
+  if (sums_out) sums_out[i] = s;
+  if (gE) {
+    const float ce = ce_base * (gscale ? gscale[0] : 1.f);
+    const float ev = to_f32(from_f32<T>(E[i]));
+    gE[i] = ce * ((float)counts[i / d] * ev - s);
+  }
+}
+
+// EMA update (scripts/train_vqvae.py:412-414): N_k, m_k moving averages + Laplace-smoothed codebook
+__global__ __launch_bounds__(256) void vq_ema_kernel(const float* __restrict__ sums, const int32_t* __restrict__ counts, int K, int d,
+                                                     float decay, float eps, float* __restrict__ ema_count,
+                                                     float* __restrict__ ema_sum, float* __restrict__ E) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float nc = decay * ema_count[k] + (1.f - decay) * (float)counts[k];
+    ema_count[k] = nc;
+    s += (double)nc;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  const float n = (float)red[0];
+  for (int i = threadIdx.x; i < K * d; i += 256) {
+    const int k = i / d;
+    const float ms = decay * ema_sum[i] + (1.f - decay) * sums[i];
+    ema_sum[i] = ms;
+    const float smoothed = (ema_count[k] + eps) / (n + (float)K * eps) * n;
+    E[i] = ms / smoothed;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int vq_chunk(int K, int d_pad, size_t esize) {
+  int kc = VQ_MAX_CHUNK;
+  while (kc > 16 && (size_t)kc * d_pad * esize > 64 * 1024) kc >>= 1;
+  const int kpad = (K + 15) / 16 * 16;
+  if (kc > kpad) kc = kpad;
+  return kc;
+}
+static int vq_grid(int64_t N, int NT) {
+  const int64_t nb = (N + 4 * NT * 16 - 1) / (4 * NT * 16);
+  return (int)(nb < 512 ? (nb < 1 ? 1 : nb) : 512);
+}
+#define VQ_NT 4
+#define VQ_FIX_WAVES 2048
+#define VQ_BWD_WGS 128
+
+struct VqLayout { size_t hdr, en, partial, partial_fix, hist, counts_fix, namb, total; int grid; };
+static VqLayout vq_layout(int64_t N, int K) {
+  VqLayout L;
+  L.grid = vq_grid(N, VQ_NT);
+  size_t o = 0;
+  L.hdr = o; o += 256;
+  L.en = o; o += ((size_t)K * 4 + 255) / 256 * 256;
+  L.partial = o; o += (size_t)L.grid * 4 * 4;          // partial_fix follows contiguously (finalize sums both)
+  L.partial_fix = o; o += (size_t)VQ_FIX_WAVES * 4;
+  o = (o + 255) / 256 * 256;
+  L.counts_fix = o; o += ((size_t)K * 4 + 255) / 256 * 256;
+  L.namb = o; o += 256;
+  L.hist = o; o += (size_t)L.grid * K * 4;
+  L.total = o;
+  return L;
+}
+
+template <typename T, int NF>
+static int launch_vq(const void* z, const float* E, int64_t N, int K, int d, int32_t* idx, void* zq, float* stats,
+                     int32_t* counts, char* ws, hipStream_t st) {
+  typedef typename DT<T>::frag_t frag_t;
+  const VqLayout L = vq_layout(N, K);
+  const int d_pad = NF * DT<T>::FE * 4;
+  const int Kc = vq_chunk(K, d_pad, sizeof(T));
+  VqHeader* hdr = (VqHeader*)(ws + L.hdr);
+  float* en = (float*)(ws + L.en);
+  // zero header, fixup counters (everything between hdr and hist)
+  FRL_HIP(hipMemsetAsync(ws, 0, L.hist, st));
+  hipLaunchKernelGGL((vq_prep_kernel<T>), dim3((K + 255) / 256), dim3(256), 0, st, E, K, d, en, hdr);
+  const size_t lds = (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc * 4 + (size_t)K * 4;
+  if (lds > 160 * 1024) return frl_fail(-3, "vq_assign: LDS budget exceeded (K too large for histogram)");
+  auto kern = vq_assign_kernel<T, NF, VQ_NT>;
+  if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(L.grid), dim3(256), lds, st, (const T*)z, E, en, hdr, N, K, d, Kc, idx, (T*)zq,
+                     (float*)(ws + L.partial), (int32_t*)(ws + L.hist));
+  const int64_t rpw = ((N + VQ_FIX_WAVES - 1) / VQ_FIX_WAVES + 63) / 64 * 64;
+  hipLaunchKernelGGL((vq_fixup_kernel<T>), dim3(VQ_FIX_WAVES / 4), dim3(256), (size_t)4 * d * sizeof(double), st,
+                     (const T*)z, E, N, K, d, rpw, idx, (T*)zq, (float*)(ws + L.partial_fix),
+                     (int32_t*)(ws + L.counts_fix), (int32_t*)(ws + L.namb));
+  hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)(ws + L.partial),
+                     L.grid * 4 + VQ_FIX_WAVES, (const int32_t*)(ws + L.hist), L.grid, K,
+                     (const int32_t*)(ws + L.counts_fix), (const int32_t*)(ws + L.namb), N, counts, stats);
+  return frl_check_launch("vq_assign");
+}
+
+static int vq_bwd_chunk(int K, int d) {
+  int kc = K;
+  while ((size_t)kc * d * 4 > 96 * 1024 && kc > 1) kc = (kc + 1) / 2;
+  return kc;
+}
+
+extern "C" {
+
+size_t frl_vq_workspace_bytes(int64_t N, int K, int d) {
+  const VqLayout L = vq_layout(N, K);
+  const size_t bwd = (size_t)VQ_BWD_WGS * K * d * 4 + (size_t)K * d * 4;
+  return L.total > bwd ? L.total : bwd;
+}
+
+// z [N][d] (dtype), E [K][d] f32 master codebook.  Outputs: idx_out [N] int32, zq_out [N][d] (dtype, the
+// codebook rows rounded to dtype), stats_out [4] f32 = {sum ||z - z_q||^2, perplexity, #rows re-evaluated in
+// float64, 0}, counts_out [K] int32 code usage.  In bf16 mode distances are taken to the bf16-rounded codebook.
+int frl_vq_assign_fwd(const void* z, const float* E, int64_t N, int K, int d, int32_t* idx_out, void* zq_out,
+                      float* stats_out, int32_t* counts_out, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (N <= 0 || K <= 0 || d <= 0) return frl_fail(-2, "vq_assign: empty input");
+  if (d > 256) return frl_fail(-2, "vq_assign: d > 256 unsupported");
+  if (ws_bytes < frl_vq_workspace_bytes(N, K, d)) return frl_fail(-4, "vq_assign: workspace too small");
+  char* w = (char*)ws;
+  // partial_fix sits right after partial so that finalize sums one contiguous array
+  if (dtype == FRL_F32) {
+    if (d <= 16) return launch_vq<float, 4>(z, E, N, K, d, idx_out, zq_out, stats_out, counts_out, w, stream);
+    if (d <= 32) return launch_vq<float, 8>(z, E, N, K, d, idx_out, zq_out, stats_out, counts_out, w, stream);
+    if (d <= 64) return launch_vq<float, 16>(z, E, N, K, d, idx_out, zq_out, stats_out, counts_out, w, stream);
+    if (d <= 128) return launch_vq<float, 32>(z, E, N, K, d, idx_out, zq_out, stats_out, counts_out, w, stream);
+    return frl_fail(-2, "vq_assign: d > 128 unsupported in f32 mode");
+  } else if (dtype == FRL_BF16) {
+    if (d <= 32) return launch_vq<bf16, 1>(z, E, N, K, d, idx_out, zq_out, stats_out, counts_out, w, stream);
+    if (d <= 64) return launch_vq<bf16, 2>(z, E, N, K, d, idx_out, zq_out, stats_out, counts_out, w, stream);
+    if (d <= 128) return launch_vq<bf16, 4>(z, E, N, K, d, idx_out, zq_out, stats_out, counts_out, w, stream);
+    return launch_vq<bf16, 8>(z, E, N, K, d, idx_out, zq_out, stats_out, counts_out, w, stream);
+  }
+  return frl_fail(-2, "vq_assign: bad dtype");
+}
+
+// g_z = g_out + gscale * beta * 2/(N d) * (z - e_idx);  g_E[k] = gscale * 2/(N d) * (n_k e_k - sum_{idx=k} z)
+// gscale: device scalar (upstream gradient of vq_loss), may be null (=1).  g_out may be null (=0).
+// g_z / g_E may be null to skip.  sums_out (optional, [K][d] f32) receives the per-code sums of z.
+int frl_vq_bwd(const void* g_out, const void* z, const float* E, const int32_t* idx, const int32_t* counts,
+               const float* gscale, float beta, int64_t N, int K, int d, void* g_z_out, float* g_E_out,
+               float* sums_out, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (N <= 0) return frl_fail(-2, "vq_bwd: empty input");
+  if (ws_bytes < frl_vq_workspace_bytes(N, K, d)) return frl_fail(-4, "vq_bwd: workspace too small");
+  const int Kc = vq_bwd_chunk(K, d);
+  const size_t lds = (size_t)Kc * d * 4;
+  const int64_t rows = (N + VQ_BWD_WGS - 1) / VQ_BWD_WGS;
+  const float cz = beta * 2.f / ((float)N * (float)d), ce = 2.f / ((float)N * (float)d);
+  float* slab = (float*)ws;
+  if (dtype == FRL_F32) {
+    auto kern = vq_bwd_kernel<float>;
+    if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(VQ_BWD_WGS), dim3(256), lds, stream, (const float*)g_out, (const float*)z, E, idx, gscale,
+                       cz, N, K, d, Kc, rows, (float*)g_z_out, slab);
+    hipLaunchKernelGGL((vq_code_reduce_kernel<float>), dim3((unsigned)(((int64_t)K * d + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)slab, VQ_BWD_WGS, E, counts, gscale, ce, K, d, g_E_out, sums_out);
+  } else if (dtype == FRL_BF16) {
+    auto kern = vq_bwd_kernel<bf16>;
+    if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(VQ_BWD_WGS), dim3(256), lds, stream, (const bf16*)g_out, (const bf16*)z, E, idx, gscale,
+                       cz, N, K, d, Kc, rows, (bf16*)g_z_out, slab);
+    hipLaunchKernelGGL((vq_code_reduce_kernel<bf16>), dim3((unsigned)(((int64_t)K * d + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)slab, VQ_BWD_WGS, E, counts, gscale, ce, K, d, g_E_out, sums_out);
+  } else return frl_fail(-2, "vq_bwd: bad dtype");
+  return frl_check_launch("vq_bwd");
+}
+
+// EMA codebook update from this batch's assignments: counts [K] int32 and per-code sums [K][d] f32
+// (both produced by frl_vq_assign_fwd / frl_vq_bwd(sums_out)).  Updates ema_count, ema_sum, E in place.
+int frl_vq_ema_update(const float* sums, const int32_t* counts, int K, int d, float decay, float eps, float* ema_count,
+                      float* ema_sum, float* E, hipStream_t stream) {
+  hipLaunchKernelGGL(vq_ema_kernel, dim3(1), dim3(256), 0, stream, sums, counts, K, d, decay, eps, ema_count, ema_sum, E);
+  return frl_check_launch("vq_ema_update");
+}
+
+}  // extern "C"

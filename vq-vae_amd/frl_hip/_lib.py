@@ -1,0 +1,64 @@
+"""ctypes loader for libfrlhip.so (the C-ABI boundary declared in include/frl_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the shared library is missing or a call
+fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfrlhip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+_lib = None
+
+
+class FrlHipError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); kept in sync with include/frl_hip.h (tests check every symbol resolves)
+P, I, L, F, S = c_void_p, c_int, c_int64, c_float, c_size_t
+SIGNATURES = {
+    "frl_version": (c_int, []),
+    "frl_last_error": (c_char_p, []),
+    "frl_device_arch": (c_int, [c_char_p, I]),
+    "frl_conv1x1_fwd": (c_int, [P, P, P, P, L, I, I, I, I, P]),
+    "frl_conv1x1_bwd_data": (c_int, [P, P, I, P, P, L, I, I, I, P]),
+    "frl_conv1x1_bwd_weight_workspace_bytes": (S, [L, I, I]),
+    "frl_conv1x1_bwd_weight": (c_int, [P, P, I, P, P, P, L, I, I, I, P, S, P]),
+    "frl_conv_tap_bwd_weight": (c_int, [P, P, I, P, P, L, L, P, L, I, I, I, I, I, I, P, S, I, P]),
+    "frl_vq_workspace_bytes": (S, [L, I, I]),
+    "frl_vq_assign_fwd": (c_int, [P, P, L, I, I, P, P, P, P, I, P, S, P]),
+    "frl_vq_bwd": (c_int, [P, P, P, P, P, P, F, L, I, I, P, P, P, I, P, S, P]),
+    "frl_vq_ema_update": (c_int, [P, P, I, I, F, F, P, P, P, P]),
+}
+
+
+def load():
+    """Loads the library once; raises FrlHipError when it is absent (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FrlHipError(
+            f"{LIB_PATH} not found: build it with `python vq-vae_amd/build.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and library drift apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().frl_last_error()
+        raise FrlHipError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
