@@ -1,0 +1,141 @@
+/* frl_hip.h -- C ABI of libfrlhip.so: the MI355X (gfx950) VQ-VAE training hot path.
+ *
+ * The reference (nnnagle/vq-vae) is pure Python/PyTorch and has NO native plugin interface; the boundary these
+ * entry points replace is the set of torch ops the reference's hot path executes.  Each
+ * declaration cites the reference call site (file:line under /root/reference) whose forward and autograd backward
+ * it stands in for.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative code on failure; frl_last_error() gives the thread-local text;
+ *   - all pointers are BORROWED DEVICE pointers (owned by the caller, e.g. torch tensors); the library allocates
+ *     nothing user-visible; scratch comes from a caller-provided workspace sized by *_workspace_bytes();
+ *   - explicit hipStream_t (void*) argument, no global state: functions are re-entrant and graph-capturable;
+ *   - activations are NHWC rows [P][C] (C contiguous) of `dtype` (FRL_F32 = 0 | FRL_BF16 = 1);
+ *     parameters and their gradients are float32 in the reference's own layouts (OIHW / [Cout][Cin][k]);
+ *   - act: 0 none, 1 relu, 2 sigmoid.  Backward entry points take the activation OUTPUT y to apply act'(y).
+ */
+#ifndef FRL_HIP_H
+#define FRL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* frl_stream_t; /* hipStream_t */
+
+enum { FRL_F32 = 0, FRL_BF16 = 1 };
+enum { FRL_ACT_NONE = 0, FRL_ACT_RELU = 1, FRL_ACT_SIGMOID = 2 };
+
+/* ---- library ------------------------------------------------------------------------------------------------- */
+int frl_version(void);
+const char* frl_last_error(void);
+int frl_device_arch(char* buf, int n); /* must report gfx950 */
+
+/* ---- pointwise (1x1) convolution --------------------------------------------------------------------------------
+ * nn.Conv2d(.,.,1): frl/models/conv2d_encoder.py:106-114; spatial.py:262-263; representation.py:169;
+ * conditioning.py:55-67; decoder template heads.py:128-198.  w [Cout][Cin], bias [Cout] or NULL. */
+int frl_conv1x1_fwd(const void* x, const float* w, const float* bias, void* y, int64_t P, int Cin, int Cout, int act,
+                    int dtype, frl_stream_t stream);
+int frl_conv1x1_bwd_data(const void* dy, const void* y, int act, const float* w, void* dx, int64_t P, int Cin, int Cout,
+                         int dtype, frl_stream_t stream);
+size_t frl_conv1x1_bwd_weight_workspace_bytes(int64_t P, int Cin, int Cout);
+int frl_conv1x1_bwd_weight(const void* dy, const void* y, int act, const void* x, float* dw, float* dbias, int64_t P,
+                           int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
+/* generalised weight gradient: rows are (b, t, hw); x is read at time t + toff (zero outside [0,T));
+ * dw destination strides (dso, dsi) address one tap of a [Cout][Cin][ntap] tensor (nn.Conv1d, tcn.py:56-62).
+ * flags bit0: scalar LDS fragment reads (debug), bit1: accumulate into dbias. */
+int frl_conv_tap_bwd_weight(const void* dy, const void* y, int act, const void* x, float* dw, int64_t dso, int64_t dsi,
+                            float* dbias, int64_t P, int Cin, int Cout, int HW, int T, int toff, int dtype, void* ws,
+                            size_t ws_bytes, int flags, frl_stream_t stream);
+
+/* ---- 3x3 convolution, pad 1 ------------------------------------------------------------------------------------
+ * nn.Conv2d(.,.,3,padding=1): frl/models/spatial.py:258-261 (mix_backbone), :266-272 (gate_net).
+ * x [B][H][W][Cin], w [Cout][Cin][3][3]. */
+int frl_conv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                    int act, int dtype, frl_stream_t stream);
+int frl_conv3x3_bwd_data(const void* dy, const void* y, int act, const float* w, void* dx, int B, int H, int W, int Cin,
+                         int Cout, int dtype, frl_stream_t stream);
+size_t frl_conv3x3_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int frl_conv3x3_bwd_weight(const void* dy, const void* y, int act, const void* x, float* dw, float* dbias, int B, int H,
+                           int W, int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, int flags, frl_stream_t stream);
+
+/* ---- GroupNorm over NHWC rows ----------------------------------------------------------------------------------
+ * nn.GroupNorm(G, C), eps 1e-5, per-sample statistics: frl/models/conv2d_encoder.py:117 (ReLU fused when relu=1,
+ * :119-121).  mean/rstd [B][G] f32 are saved for the backward. */
+int frl_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int B,
+                      int HW, int C, int G, float eps, int relu, int dtype, frl_stream_t stream);
+size_t frl_groupnorm_bwd_workspace_bytes(int B, int C, int G);
+int frl_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                      const float* rstd, void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int G, int relu,
+                      int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
+
+/* ---- EdgeAwareSmoothingConv2D fixed stencils -------------------------------------------------------------------
+ * Sobel/4 depthwise gradients (frl/models/spatial.py:240-249,295-296): g [B][H][W][2C] = cat[dx, dy]. */
+int frl_sobel_fwd(const void* x, void* g, int B, int H, int W, int C, int dtype, frl_stream_t stream);
+int frl_sobel_bwd(const void* dg, void* dx, int B, int H, int W, int C, int dtype, frl_stream_t stream);
+/* directional bank + rank-R mixing (spatial.py:224-237,300-331): a_logit [P][8R] (k*R+r), b_logit [P][C*R] (c*R+r);
+ * outputs smoothed, residual = x - smoothed, and the softmaxed maps a_soft / b_soft saved for the backward. */
+int frl_edge_smooth_stencil_fwd(const void* x, const void* a_logit, const void* b_logit, void* smoothed, void* residual,
+                                void* a_soft, void* b_soft, int B, int H, int W, int C, int R, int coarse_dilation,
+                                int dtype, frl_stream_t stream);
+int frl_edge_smooth_stencil_bwd(const void* d_smoothed, const void* x, const void* a_soft, const void* b_soft, void* dx,
+                                void* da_logit, void* db_logit, int B, int H, int W, int C, int R, int coarse_dilation,
+                                int dtype, frl_stream_t stream);
+/* out = smoothed + max(gate_raw, min_gate) * residual (spatial.py:333-335); n = element count */
+int frl_gate_blend_fwd(const void* smoothed, const void* residual, const void* gate_raw, float min_gate, void* out,
+                       void* gate_out, int64_t n, int dtype, frl_stream_t stream);
+int frl_gate_blend_bwd(const void* dout, const void* dgate_ext, const void* residual, const void* gate_raw, float min_gate,
+                       void* d_residual, void* d_gate_raw, int64_t n, int dtype, frl_stream_t stream);
+
+/* ---- fused TCN GatedResidualBlock ------------------------------------------------------------------------------
+ * frl/models/tcn.py:78-111 on x [B][T][HW][Cin] (npix = B*HW); conv_w [Cout][Cin][3], gate_w [Cout][Cout],
+ * proj_w [Cout][Cin] or NULL (identity residual, tcn.py:71-76). */
+int frl_tcn_block_fwd(const void* x, const float* conv_w, const float* conv_b, const float* gn_w, const float* gn_b,
+                      const float* gate_w, const float* gate_b, const float* proj_w, const float* proj_b, void* y,
+                      int64_t npix, int HW, int T, int Cin, int Cout, int dilation, int G, float eps, int dtype,
+                      frl_stream_t stream);
+size_t frl_tcn_block_bwd_workspace_bytes(int64_t npix, int Cout);
+int frl_tcn_block_bwd(const void* x, const void* dy, const float* conv_w, const float* conv_b, const float* gn_w,
+                      const float* gn_b, const float* gate_w, const float* gate_b, const float* proj_w,
+                      const float* proj_b, void* dconv, void* dgpre, void* normed, void* dres, float* dgamma, float* dbeta,
+                      int64_t npix, int HW, int T, int Cin, int Cout, int dilation, int G, float eps, int dtype, void* ws,
+                      size_t ws_bytes, frl_stream_t stream);
+int frl_tcn_block_bwd_data(const void* dconv, const void* dres, const float* conv_w, const float* proj_w, void* dx,
+                           int64_t npix, int HW, int T, int Cin, int Cout, int dilation, int dtype, frl_stream_t stream);
+
+/* ---- FiLM modulation, time mean, add ---------------------------------------------------------------------------
+ * z = gamma * h + beta broadcast over T (frl/models/representation.py:369-372); h [B][T][HW][C], gamma [B][HW][C]. */
+int frl_film_modulate_fwd(const void* h, const void* gamma, const void* beta, void* out, int64_t B, int T, int64_t HW,
+                          int C, int dtype, frl_stream_t stream);
+int frl_film_modulate_bwd(const void* dout, const void* h, const void* gamma, void* dh, void* dgamma, void* dbeta,
+                          int64_t B, int T, int64_t HW, int C, int dtype, frl_stream_t stream);
+int frl_mean_time_fwd(const void* tile, void* out, int64_t B, int T, int64_t HWC, int dtype, frl_stream_t stream);
+int frl_add(const void* a, const void* b, void* out, int64_t n, int dtype, frl_stream_t stream);
+
+/* ---- masked L2 reconstruction loss -----------------------------------------------------------------------------
+ * frl/losses/reconstruction.py:95-139 (loss_type "l2", reduction "mean"); out = {mean, n_valid_elements}. */
+size_t frl_mse_workspace_bytes(void);
+int frl_mse_fwd(const void* pred, const void* target, const uint8_t* mask, int64_t P, int C, float* out, int dtype,
+                void* ws, size_t ws_bytes, frl_stream_t stream);
+int frl_mse_bwd(const void* pred, const void* target, const uint8_t* mask, const float* gscale, const float* stats,
+                int64_t P, int C, void* dpred, int dtype, frl_stream_t stream);
+
+/* ---- vector quantizer ------------------------------------------------------------------------------------------
+ * Not in the reference tree; constants frl/config/frl_model_v0.yaml:29-35,
+ * scripts/train_vqvae.py:410-436.  idx bit-exact vs float64 argmin (first index on ties). */
+size_t frl_vq_workspace_bytes(int64_t N, int K, int d);
+int frl_vq_assign_fwd(const void* z, const float* E, int64_t N, int K, int d, int32_t* idx_out, void* zq_out,
+                      float* stats_out, int32_t* counts_out, int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
+int frl_vq_bwd(const void* g_out, const void* z, const float* E, const int32_t* idx, const int32_t* counts,
+               const float* gscale, float beta, int64_t N, int K, int d, void* g_z_out, float* g_E_out, float* sums_out,
+               int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
+int frl_vq_ema_update(const float* sums, const int32_t* counts, int K, int d, float decay, float eps, float* ema_count,
+                      float* ema_sum, float* E, frl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRL_HIP_H */

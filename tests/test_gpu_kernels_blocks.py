@@ -1,0 +1,228 @@
+"""GPU parity of GroupNorm, 3x3 conv, stencils, fused TCN block and streaming ops vs the CPU oracle (float64 autograd)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import frl_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+MODES = [(torch.float32, 3e-6, 2e-5), (torch.bfloat16, 3e-2, 3e-2)]  # (dtype, activation tol, weight-grad tol) relative to max|ref|
+
+
+def rel_err(got, ref):
+    ref = ref.double()
+    return (got.detach().cpu().double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+
+
+def q(t, dtype):
+    """Quantise to the storage dtype and return float64 master of the quantised value."""
+    return t.to(dtype).double()
+
+
+def nhwc(t):  # [B,C,H,W] -> [B,H,W,C]
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("dtype,atol,wtol", MODES)
+@pytest.mark.parametrize("B,HW,C,G,relu", [(3, 1024, 128, 8, True), (2, 64, 16, 4, True), (2, 64, 8, 4, False), (5, 100, 64, 8, False)])
+def test_groupnorm(dtype, atol, wtol, B, HW, C, G, relu):
+    from frl_hip import ops
+    g = torch.Generator().manual_seed(B * HW + C)
+    x = q(torch.randn(B, HW, C, generator=g) * 1.5 + 0.3, dtype).requires_grad_(True)
+    gam = (torch.rand(C, generator=g) + 0.5).double().requires_grad_(True)
+    bet = (torch.randn(C, generator=g) * 0.2).double().requires_grad_(True)
+    dy = q(torch.randn(B, HW, C, generator=g), dtype)
+    ref = O.group_norm(x.permute(0, 2, 1), G, gam, bet).permute(0, 2, 1)
+    if relu:
+        ref = F.relu(ref)
+    ref.backward(dy)
+    xd, dyd = x.detach().to(dtype).to(DEV), dy.to(dtype).to(DEV)
+    gd, bd = gam.detach().float().to(DEV), bet.detach().float().to(DEV)
+    y, mean, rstd = ops.groupnorm_fwd(xd, gd, bd, G, 1e-5, relu)
+    assert rel_err(y.float(), ref) <= atol
+    dx, dg, db = ops.groupnorm_bwd(dyd, xd, gd, bd, mean, rstd, G, relu)
+    assert rel_err(dx.float(), x.grad) <= atol * 2
+    assert rel_err(dg, gam.grad) <= wtol and rel_err(db, bet.grad) <= wtol
+
+
+@pytest.mark.parametrize("dtype,atol,wtol", MODES)
+@pytest.mark.parametrize("B,H,W,cin,cout,act", [(2, 32, 32, 128, 64, 1), (1, 8, 8, 16, 8, 1), (2, 8, 8, 8, 8, 2), (1, 13, 21, 64, 64, 0),
+                                                (1, 16, 16, 64, 128, 2)])
+def test_conv3x3(dtype, atol, wtol, B, H, W, cin, cout, act):
+    from frl_hip import ops
+    g = torch.Generator().manual_seed(H * W + cin + cout)
+    x = q(torch.randn(B, cin, H, W, generator=g), dtype).requires_grad_(True)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5))
+    wq = (q(w, dtype) if dtype == torch.bfloat16 else w.double()).requires_grad_(True)
+    b = (torch.randn(cout, generator=g) * 0.1).double().requires_grad_(True)
+    y = F.conv2d(x, wq, b, padding=1)
+    y = F.relu(y) if act == 1 else torch.sigmoid(y) if act == 2 else y
+    dy = q(torch.randn(B, cout, H, W, generator=g), dtype)
+    xd = nhwc(x.detach()).to(dtype).to(DEV)
+    wd, bd = w.float().to(DEV), b.detach().float().to(DEV)
+    yd = ops.conv3x3_fwd(xd, wd, bd, act)
+    assert rel_err(yd.float(), nhwc(y.detach())) <= atol
+    # backward through the same activation using the DEVICE output as the mask (as autograd does)
+    yq = q(yd.float().cpu(), dtype).permute(0, 3, 1, 2)
+    x2 = x.detach().clone().requires_grad_(True)
+    w2 = wq.detach().clone().requires_grad_(True)
+    b2 = b.detach().clone().requires_grad_(True)
+    pre = F.conv2d(x2, w2, b2, padding=1)
+    dpre = dy * ((yq > 0).double() if act == 1 else (yq * (1 - yq)) if act == 2 else 1.0)
+    pre.backward(dpre)
+    dyd = nhwc(dy).to(dtype).to(DEV)
+    dx = ops.conv3x3_bwd_data(dyd, wd, yd if act else None, act)
+    assert rel_err(dx.float(), nhwc(x2.grad)) <= atol * 2
+    for scalar in (False, True):
+        dw, db = ops.conv3x3_bwd_weight(dyd, xd, yd if act else None, act, scalar_frags=scalar)
+        assert rel_err(dw, w2.grad) <= wtol * 2 and rel_err(db, b2.grad) <= wtol * 2
+
+
+@pytest.mark.parametrize("dtype,atol,wtol", MODES)
+@pytest.mark.parametrize("B,H,W,C", [(2, 32, 32, 64), (1, 8, 8, 8), (1, 9, 13, 16)])
+def test_sobel(dtype, atol, wtol, B, H, W, C):
+    from frl_hip import ops
+    g = torch.Generator().manual_seed(C + H)
+    x = q(torch.randn(B, C, H, W, generator=g), dtype).requires_grad_(True)
+    sx = (torch.tensor([[-1., 0., 1.], [-2., 0., 2.], [-1., 0., 1.]]) / 4).double().reshape(1, 1, 3, 3).expand(C, 1, 3, 3)
+    sy = (torch.tensor([[-1., -2., -1.], [0., 0., 0.], [1., 2., 1.]]) / 4).double().reshape(1, 1, 3, 3).expand(C, 1, 3, 3)
+    ref = torch.cat([F.conv2d(x, sx, padding=1, groups=C), F.conv2d(x, sy, padding=1, groups=C)], 1)
+    dg = q(torch.randn(B, 2 * C, H, W, generator=g), dtype)
+    ref.backward(dg)
+    gd = ops.sobel_fwd(nhwc(x.detach()).to(dtype).to(DEV))
+    assert rel_err(gd.float(), nhwc(ref.detach())) <= atol
+    dx = ops.sobel_bwd(nhwc(dg).to(dtype).to(DEV))
+    assert rel_err(dx.float(), nhwc(x.grad)) <= atol * 2
+
+
+def _smooth_ref(x, al, bl, R, dil):
+    b, c, hh, ww = x.shape
+    k = 8
+    tmpl = [[[0., 0., 0.], [1 / 3, 1 / 3, 1 / 3], [0., 0., 0.]], [[0., 1 / 3, 0.], [0., 1 / 3, 0.], [0., 1 / 3, 0.]],
+            [[1 / 3, 0., 0.], [0., 1 / 3, 0.], [0., 0., 1 / 3]], [[0., 0., 1 / 3], [0., 1 / 3, 0.], [1 / 3, 0., 0.]]]
+    a = torch.softmax(al.reshape(b, k, R, hh, ww), dim=1)
+    bw = torch.softmax(bl.reshape(b, c, R, hh, ww), dim=2)
+    slot = torch.zeros(b, c, R, hh, ww, dtype=x.dtype)
+    for i in range(4):
+        filt = torch.tensor(tmpl[i], dtype=x.dtype).reshape(1, 1, 3, 3).expand(c, 1, 3, 3)
+        fine = F.conv2d(x, filt, padding=1, groups=c)
+        coarse = F.conv2d(x, filt, padding=dil, dilation=dil, groups=c)
+        slot = slot + fine.unsqueeze(2) * a[:, 2 * i].unsqueeze(1) + coarse.unsqueeze(2) * a[:, 2 * i + 1].unsqueeze(1)
+    sm = (bw * slot).sum(2)
+    return sm, x - sm
+
+
+@pytest.mark.parametrize("dtype,atol,wtol", MODES)
+@pytest.mark.parametrize("B,H,W,C,R", [(2, 32, 32, 64, 4), (1, 8, 8, 8, 4), (1, 7, 11, 16, 2), (1, 8, 8, 48, 4)])
+def test_edge_smooth_stencil(dtype, atol, wtol, B, H, W, C, R):
+    from frl_hip import ops
+    g = torch.Generator().manual_seed(C * R + H)
+    x = q(torch.randn(B, C, H, W, generator=g), dtype).requires_grad_(True)
+    al = q(torch.randn(B, 8 * R, H, W, generator=g), dtype).requires_grad_(True)
+    bl = q(torch.randn(B, C * R, H, W, generator=g), dtype).requires_grad_(True)
+    sm, res = _smooth_ref(x, al, bl, R, 3)
+    xd, ald, bld = (nhwc(t.detach()).to(dtype).to(DEV) for t in (x, al, bl))
+    smd, resd, asoft, bsoft = ops.edge_smooth_fwd(xd, ald, bld, R, 3)
+    assert rel_err(smd.float(), nhwc(sm.detach())) <= atol
+    assert rel_err(resd.float(), nhwc(res.detach())) <= atol
+    ds = q(torch.randn(B, C, H, W, generator=g), dtype)
+    sm.backward(ds)
+    dx, da, db = ops.edge_smooth_bwd(nhwc(ds).to(dtype).to(DEV), xd, asoft, bsoft, R, 3)
+    assert rel_err(dx.float(), nhwc(x.grad)) <= atol * 3
+    assert rel_err(da.float(), nhwc(al.grad)) <= atol * 3
+    assert rel_err(db.float(), nhwc(bl.grad)) <= atol * 3
+
+
+@pytest.mark.parametrize("dtype,atol,wtol", MODES)
+@pytest.mark.parametrize("B,T,HW,cin,cout,G,dil", [(2, 5, 64, 8, 8, 4, 1), (2, 5, 64, 8, 8, 4, 4), (1, 5, 1024, 64, 64, 8, 2), (3, 10, 50, 64, 64, 8, 4),
+                                                   (1, 5, 37, 16, 8, 4, 1), (1, 15, 16, 64, 64, 8, 4), (1, 5, 32, 12, 64, 8, 2)])
+def test_tcn_block(dtype, atol, wtol, B, T, HW, cin, cout, G, dil):
+    from frl_hip import ops
+    g = torch.Generator().manual_seed(T * HW + cin + cout + dil)
+    prefix = "b."
+    st = {}
+    st[prefix + "conv.weight"] = torch.randn(cout, cin, 3, generator=g) / (3 * cin) ** 0.5
+    st[prefix + "conv.bias"] = torch.randn(cout, generator=g) * 0.1
+    st[prefix + "norm.weight"] = torch.rand(cout, generator=g) + 0.5
+    st[prefix + "norm.bias"] = torch.randn(cout, generator=g) * 0.2
+    st[prefix + "gate.weight"] = torch.randn(cout, cout, 1, generator=g) / cout ** 0.5
+    st[prefix + "gate.bias"] = torch.randn(cout, generator=g) * 0.1
+    if cin != cout:
+        st[prefix + "projection.weight"] = torch.randn(cout, cin, 1, generator=g) / cin ** 0.5
+        st[prefix + "projection.bias"] = torch.randn(cout, generator=g) * 0.1
+    mm = {"conv.weight", "gate.weight", "projection.weight"}
+    ref_st = {k: ((q(v, dtype) if (dtype == torch.bfloat16 and k[len(prefix):] in mm) else v.double()).requires_grad_(True))
+              for k, v in st.items()}
+    x = q(torch.randn(B, T, HW, cin, generator=g), dtype).requires_grad_(True)     # [B,T,HW,C]
+    xr = x.permute(0, 2, 3, 1).reshape(B * HW, cin, T)                                # [N,C,T]
+    yr = O.tcn_block_forward(ref_st, xr, dil, G, prefix)
+    y_ref = yr.reshape(B, HW, cout, T).permute(0, 3, 1, 2)
+    dy = q(torch.randn(B, T, HW, cout, generator=g), dtype)
+    y_ref.backward(dy)
+    dev = {k: v.float().to(DEV) for k, v in st.items()}
+    args = (dev[prefix + "conv.weight"], dev[prefix + "conv.bias"], dev[prefix + "norm.weight"], dev[prefix + "norm.bias"],
+            dev[prefix + "gate.weight"], dev[prefix + "gate.bias"], dev.get(prefix + "projection.weight"), dev.get(prefix + "projection.bias"))
+    if args[6] is not None:
+        args = args[:6] + (args[6].reshape(cout, cin).contiguous(), args[7])
+    xd = x.detach().to(dtype).to(DEV)
+    yd = ops.tcn_block_fwd(xd, *args, dil, G)
+    assert rel_err(yd.float(), y_ref.detach()) <= atol * 2
+    gr = ops.tcn_block_bwd(xd, dy.to(dtype).to(DEV), *args, dil, G)
+    assert rel_err(gr["dx"].float(), x.grad) <= atol * 4
+    names = dict(conv_w="conv.weight", conv_b="conv.bias", gn_w="norm.weight", gn_b="norm.bias", gate_w="gate.weight", gate_b="gate.bias",
+                 proj_w="projection.weight", proj_b="projection.bias")
+    for kk, nm in names.items():
+        if kk in gr:
+            assert rel_err(gr[kk].reshape(ref_st[prefix + nm].shape), ref_st[prefix + nm].grad) <= wtol * 4, kk
+
+
+@pytest.mark.parametrize("dtype,atol,wtol", MODES)
+def test_streaming_ops(dtype, atol, wtol):
+    from frl_hip import ops
+    g = torch.Generator().manual_seed(1)
+    B, T, H, W, C = 2, 5, 8, 8, 12
+    # mean over time
+    tile = q(torch.randn(B, T, H, W, 16, generator=g), dtype)
+    assert rel_err(ops.mean_time(tile.to(dtype).to(DEV)).float(), tile.mean(1)) <= atol
+    # FiLM
+    h = q(torch.randn(B, T, H * W, C, generator=g), dtype).requires_grad_(True)
+    ga = q(torch.randn(B, H * W, C, generator=g), dtype).requires_grad_(True)
+    be = q(torch.randn(B, H * W, C, generator=g), dtype).requires_grad_(True)
+    out = ga.unsqueeze(1) * h + be.unsqueeze(1)
+    do = q(torch.randn(B, T, H * W, C, generator=g), dtype)
+    out.backward(do)
+    hd, gd, bd = (t.detach().to(dtype).to(DEV) for t in (h, ga, be))
+    assert rel_err(ops.film_modulate_fwd(hd, gd, bd).float(), out.detach()) <= atol
+    dh, dg, db = ops.film_modulate_bwd(do.to(dtype).to(DEV), hd, gd)
+    assert rel_err(dh.float(), h.grad) <= atol and rel_err(dg.float(), ga.grad) <= atol * 2 and rel_err(db.float(), be.grad) <= atol * 2
+    # MSE with and without mask
+    p = q(torch.randn(300, 64, generator=g), dtype).requires_grad_(True)
+    t = q(torch.randn(300, 64, generator=g), dtype)
+    for use_mask in (False, True):
+        mask = (torch.rand(300, generator=g) > 0.3) if use_mask else None
+        p.grad = None
+        loss = O.reconstruction_loss_l2(p, t, mask.unsqueeze(1).expand(300, 64) if use_mask else None)
+        (loss * 0.7).backward()
+        md = mask.to(torch.uint8).to(DEV) if use_mask else None
+        st = ops.mse_fwd(p.detach().to(dtype).to(DEV), t.to(dtype).to(DEV), md)
+        assert abs(st[0].item() - loss.item()) <= 1e-5 * loss.item()
+        dp = ops.mse_bwd(p.detach().to(dtype).to(DEV), t.to(dtype).to(DEV), md, torch.tensor([0.7], device=DEV), st)
+        assert rel_err(dp.float(), p.grad) <= atol
+    # gate blend
+    for mg in (0.0, 0.55):
+        sm = q(torch.randn(64, 16, generator=g), dtype).requires_grad_(True)
+        rs = q(torch.randn(64, 16, generator=g), dtype).requires_grad_(True)
+        gr_ = q(torch.rand(64, 16, generator=g), dtype).requires_grad_(True)
+        gate = gr_.clamp(min=mg) if mg > 0 else gr_
+        o = sm + gate * rs
+        do, dge = q(torch.randn(64, 16, generator=g), dtype), q(torch.randn(64, 16, generator=g), dtype)
+        (o * do + gate * dge).sum().backward()
+        od, gd_ = ops.gate_blend_fwd(*(t.detach().to(dtype).to(DEV) for t in (sm, rs, gr_)), mg)
+        assert rel_err(od.float(), o.detach()) <= atol and rel_err(gd_.float(), gate.detach()) <= atol
+        dres, dgraw = ops.gate_blend_bwd(do.to(dtype).to(DEV), dge.to(dtype).to(DEV), rs.detach().to(dtype).to(DEV), gr_.detach().to(dtype).to(DEV), mg)
+        assert rel_err(dres.float(), rs.grad) <= atol and rel_err(dgraw.float(), gr_.grad) <= atol
+    a, b = q(torch.randn(128, 8, generator=g), dtype), q(torch.randn(128, 8, generator=g), dtype)
+    assert rel_err(ops.add(a.to(dtype).to(DEV), b.to(dtype).to(DEV)).float(), a + b) <= atol

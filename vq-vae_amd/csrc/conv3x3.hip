@@ -1,0 +1,416 @@
+// 3x3 convolution (pad 1, stride 1) over NHWC tiles as an implicit GEMM on the matrix cores.
+//   Reference call sites: mix_backbone Conv2d(2C, gh, 3, pad=1)+ReLU  frl/models/spatial.py:258-261,297 (K6)
+//                         gate_net Conv2d(C,gh,3)+ReLU, Conv2d(gh,C,3)+Sigmoid  spatial.py:266-272,332 (K11)
+// Forward / bwd_data (same kernel on the flipped, transposed weight view):
+//   workgroup = 8 x 16 output pixels x (up to) 64 output channels; 4 waves x 2 image rows each;
+//   input halo tile (10 x 18 pixels x CK channels, 16-B skewed rows) and the chunk's 9-tap weights (packed MFMA A
+//   fragments) live in LDS; B fragments are the lane-quarter image of the shifted pixels read by ds_read_b128.
+// bwd_weight: K = pixels.  dY tile and X halo staged row-major in LDS, k-strided fragments fetched with
+//   ds_read_b64_tr_b16; every wave owns one 16-channel input block x all 9 taps x 64 output channels in registers;
+//   per-workgroup f32 slabs are summed in fixed order afterwards.
+// Roofline: MFMA (147 456 FLOP/px at 128->64 vs 384 B/px bf16 = 384 FLOP/B, above the 312 FLOP/B balance point).
+#include "frl_common.hpp"
+#include "frl_host.hpp"
+
+#define C3_TH 8
+#define C3_TW 16
+#define C3_HP (C3_TH + 2)
+#define C3_WP (C3_TW + 2)
+
+template <typename T> struct C3 {
+  static constexpr int PADE = 16 / sizeof(T);   // 16-byte skew per pixel row
+};
+
+// ------------------------------------------------------------------------------------------------
+// staging helpers
+// ------------------------------------------------------------------------------------------------
+// halo[(hy*18+hx)*pitch + c] = X[b, y0+hy-1, x0+hx-1, ck + c] (* act'(mask)) or 0
+template <typename T>
+__device__ __forceinline__ void stage_halo(T* __restrict__ halo, int pitch, const T* __restrict__ X, const T* __restrict__ M,
+                                           int mask_act, int b, int y0, int x0, int H, int W, int C, int ck, int CK, int tid) {
+  constexpr int V = DT<T>::VEC;
+  const int vpc = CK / V;
+  const bool fast = (C % V) == 0;
+  for (int i = tid; i < C3_HP * C3_WP * vpc; i += 256) {
+    const int px = i / vpc, c0 = (i % vpc) * V;
+    const int hy = px / C3_WP, hx = px % C3_WP;
+    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+    float v[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W && ck + c0 < C) {
+      const int64_t off = (((int64_t)b * H + gy) * W + gx) * C + ck + c0;
+      if (fast) {
+        Vec<T>::load(X + off, v);
+        if (M != nullptr) {
+          float m[V];
+          Vec<T>::load(M + off, m);
+#pragma unroll
+          for (int e = 0; e < V; ++e) v[e] *= act_bwd_from_y(m[e], mask_act);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+          if (ck + c0 + e < C) {
+            v[e] = to_f32(X[off + e]);
+            if (M != nullptr) v[e] *= act_bwd_from_y(to_f32(M[off + e]), mask_act);
+          }
+      }
+    }
+    Vec<T>::store(halo + px * pitch + c0, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / bwd_data
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NF>
+__global__ __launch_bounds__(256) void conv3x3_kernel(const T* __restrict__ X, const T* __restrict__ Xmask, int mask_act,
+                                                      const float* __restrict__ Wt, int64_t w_so, int64_t w_si, int tap_rev,
+                                                      const float* __restrict__ bias, T* __restrict__ Y, int B, int H, int W,
+                                                      int Cin, int Cout, int act) {
+  typedef typename DT<T>::frag_t frag_t;
+  constexpr int FE = DT<T>::FE;
+  constexpr int q = NF * FE, CK = 4 * q;
+  constexpr int pitch = CK + C3<T>::PADE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* halo = reinterpret_cast<T*>(smem);
+  frag_t* wl = reinterpret_cast<frag_t*>(smem + (size_t)C3_HP * C3_WP * pitch * sizeof(T));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, kc = lane >> 4;
+  const int tiles_x = (W + C3_TW - 1) / C3_TW, tiles_y = (H + C3_TH - 1) / C3_TH;
+  const int bid = blockIdx.x;
+  const int b = bid / (tiles_x * tiles_y), tyx = bid % (tiles_x * tiles_y);
+  const int y0 = (tyx / tiles_x) * C3_TH, x0 = (tyx % tiles_x) * C3_TW;
+  const int MB = (Cout + 15) >> 4, qo = 4 * MB;
+
+  for (int oc0 = 0; oc0 < MB; oc0 += 4) {
+    const int nmb = (MB - oc0) < 4 ? (MB - oc0) : 4;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ck = 0; ck < Cin; ck += CK) {
+      __syncthreads();
+      stage_halo<T>(halo, pitch, X, Xmask, mask_act, b, y0, x0, H, W, Cin, ck, CK, tid);
+      // weights of this (out-chunk, in-chunk): wl[((tap*4 + m)*NF + s)*64 + lane]
+      for (int i = tid; i < 9 * 4 * NF * 64; i += 256) {
+        const int ln = i & 63, fs = i >> 6;
+        const int s = fs % NF, m = (fs / NF) & 3, tap = fs / (NF * 4);
+        const int r = ln & 15, kq = ln >> 4;
+        const int oc = qo * (r >> 2) + 4 * (oc0 + m) + (r & 3);
+        const int tsrc = tap_rev ? 8 - tap : tap;
+        if constexpr (FE == 8) {
+          bf16x8 v;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int ic = ck + q * kq + 8 * s + e;
+            v[e] = (m < nmb && oc < Cout && ic < Cin) ? (bf16)Wt[oc * w_so + ic * w_si + tsrc] : (bf16)0.f;
+          }
+          wl[i] = v;
+        } else {
+          const int ic = ck + q * kq + s;
+          wl[i] = (m < nmb && oc < Cout && ic < Cin) ? Wt[oc * w_so + ic * w_si + tsrc] : 0.f;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+        frag_t bf[2][NF];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const T* hp = halo + ((2 * wave + t + dy) * C3_WP + px + dx) * pitch + q * kc;
+#pragma unroll
+          for (int s = 0; s < NF; ++s) {
+            if constexpr (FE == 8) bf[t][s] = *reinterpret_cast<const bf16x8*>(hp + 8 * s);
+            else bf[t][s] = hp[s];
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          if (m < nmb) {
+#pragma unroll
+            for (int s = 0; s < NF; ++s) {
+              const frag_t a = wl[((tap * 4 + m) * NF + s) * 64 + lane];
+#pragma unroll
+              for (int t = 0; t < 2; ++t) acc[t][m] = mfma16(a, bf[t][s], acc[t][m]);
+            }
+          }
+        }
+      }
+    }
+    // epilogue
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int gy = y0 + 2 * wave + t, gx = x0 + px;
+      if (gy >= H || gx >= W) continue;
+      T* yp = Y + (((int64_t)b * H + gy) * W + gx) * Cout;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (m >= nmb) continue;
+        const int cb = qo * kc + 4 * (oc0 + m);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = cb + r;
+          const float bb = (bias != nullptr && c < Cout) ? bias[c] : 0.f;
+          v[r] = act_fwd(acc[t][m][r] + bb, act);
+        }
+        if ((Cout & 3) == 0 && cb + 3 < Cout) {
+          if constexpr (FE == 8) *reinterpret_cast<bf16x4*>(yp + cb) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          else *reinterpret_cast<f32x4*>(yp + cb) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (cb + r < Cout) yp[cb + r] = from_f32<T>(v[r]);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bwd_weight
+// ------------------------------------------------------------------------------------------------
+template <typename T, int IBC, int OBW>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict__ dY, const T* __restrict__ Ymask, int mask_act,
+                                                            const T* __restrict__ X, float* __restrict__ slab, int B, int H, int W,
+                                                            int Cin, int Cout, int oc_base, int tiles_per_wg, int use_tr) {
+  constexpr int FE = DT<T>::FE;
+  constexpr int V = DT<T>::VEC;
+  constexpr int CK = IBC * 16;
+  constexpr int NOG = 4 / IBC;                 // wave groups along output channels
+  constexpr int OCT = NOG * OBW * 16;          // output channels per pass (64)
+  constexpr int pitchA = OCT + C3<T>::PADE, pitchB = CK + C3<T>::PADE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* ldsA = reinterpret_cast<T*>(smem);                                   // [128][pitchA]
+  T* halo = ldsA + C3_TH * C3_TW * pitchA;                                // [180][pitchB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kc = lane >> 4;
+  const int ib = wave % IBC, og = wave / IBC;
+  const int tiles_x = (W + C3_TW - 1) / C3_TW, tiles_y = (H + C3_TH - 1) / C3_TH;
+  const int ntiles = B * tiles_x * tiles_y;
+  const int t_begin = blockIdx.x * tiles_per_wg;
+  const int t_end = (t_begin + tiles_per_wg) < ntiles ? (t_begin + tiles_per_wg) : ntiles;
+  const int64_t slab_n = (int64_t)OCT * Cin * 9 + OCT;
+  float* my = slab + (int64_t)blockIdx.x * slab_n;
+  const bool fastA = (Cout % V) == 0;
+  float bsum = 0.f;
+
+  for (int ck = 0; ck < Cin; ck += CK) {
+    f32x4 acc[9][OBW];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int o = 0; o < OBW; ++o) acc[tap][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      const int b = tile / (tiles_x * tiles_y), tyx = tile % (tiles_x * tiles_y);
+      const int y0 = (tyx / tiles_x) * C3_TH, x0 = (tyx % tiles_x) * C3_TW;
+      __syncthreads();
+      // dY tile (masked by act'(y)), channels [oc_base, oc_base + OCT)
+      for (int i = tid; i < C3_TH * C3_TW * (OCT / V); i += 256) {
+        const int px = i / (OCT / V), c0 = (i % (OCT / V)) * V;
+        const int gy = y0 + px / C3_TW, gx = x0 + px % C3_TW;
+        float v[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = 0.f;
+        if (gy < H && gx < W && oc_base + c0 < Cout) {
+          const int64_t off = (((int64_t)b * H + gy) * W + gx) * Cout + oc_base + c0;
+          if (fastA) {
+            Vec<T>::load(dY + off, v);
+            if (Ymask != nullptr) {
+              float m[V];
+              Vec<T>::load(Ymask + off, m);
+#pragma unroll
+              for (int e = 0; e < V; ++e) v[e] *= act_bwd_from_y(m[e], mask_act);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e)
+              if (oc_base + c0 + e < Cout) {
+                v[e] = to_f32(dY[off + e]);
+                if (Ymask != nullptr) v[e] *= act_bwd_from_y(to_f32(Ymask[off + e]), mask_act);
+              }
+          }
+        }
+        Vec<T>::store(ldsA + px * pitchA + c0, v);
+      }
+      stage_halo<T>(halo, pitchB, X, (const T*)nullptr, 0, b, y0, x0, H, W, Cin, ck, CK, tid);
+      __syncthreads();
+      if (ck == 0 && tid < OCT) {
+        float s = 0.f;
+        for (int p = 0; p < C3_TH * C3_TW; ++p) s += to_f32(ldsA[p * pitchA + tid]);
+        bsum += s;
+      }
+      if constexpr (FE == 8) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int row = 2 * ks + (kc >> 1), col = 8 * (kc & 1);
+          bf16x8 af[OBW];
+#pragma unroll
+          for (int o = 0; o < OBW; ++o) {
+            const int ch0 = (og * OBW + o) * 16;
+            const int pb = row * C3_TW + col;
+            if (use_tr) {
+              const T* a0 = ldsA + (pb + (r16 >> 2)) * pitchA + ch0 + 4 * (r16 & 3);
+              bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0));
+              bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0 + 4 * pitchA));
+              af[o] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) af[o][j] = ldsA[(pb + j) * pitchA + ch0 + r16];
+            }
+          }
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            const int hb = (row + dy) * C3_WP + col + dx;
+            bf16x8 bfr;
+            if (use_tr) {
+              const T* a0 = halo + (hb + (r16 >> 2)) * pitchB + ib * 16 + 4 * (r16 & 3);
+              bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0));
+              bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0 + 4 * pitchB));
+              bfr = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) bfr[j] = halo[(hb + j) * pitchB + ib * 16 + r16];
+            }
+#pragma unroll
+            for (int o = 0; o < OBW; ++o) acc[tap][o] = mfma16(af[o], bfr, acc[tap][o]);
+          }
+        }
+      } else {
+#pragma unroll 2
+        for (int ks = 0; ks < C3_TH * C3_TW / 4; ++ks) {
+          const int pix = 4 * ks + kc;
+          const int row = pix / C3_TW, col = pix % C3_TW;
+          float af[OBW];
+#pragma unroll
+          for (int o = 0; o < OBW; ++o) af[o] = ldsA[pix * pitchA + (og * OBW + o) * 16 + r16];
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            const float bfr = halo[((row + dy) * C3_WP + col + dx) * pitchB + ib * 16 + r16];
+#pragma unroll
+            for (int o = 0; o < OBW; ++o) acc[tap][o] = mfma16(af[o], bfr, acc[tap][o]);
+          }
+        }
+      }
+    }
+    // slab part for this input-channel chunk: my[(ocl * Cin + ic) * 9 + tap]
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int o = 0; o < OBW; ++o)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ocl = (og * OBW + o) * 16 + kc * 4 + r, ic = ck + ib * 16 + r16;
+          if (ic < Cin) my[((int64_t)ocl * Cin + ic) * 9 + tap] = acc[tap][o][r];
+        }
+  }
+  if (tid < OCT) my[(int64_t)OCT * Cin * 9 + tid] = bsum;
+}
+
+// out[oc][j] = sum_wg slab[wg][ocl][j]; rows beyond Cout are dropped
+__global__ void conv3x3_slab_reduce_kernel(const float* __restrict__ slab, int nslab, int OCT, int Cin9, int oc_base, int Cout,
+                                           float* __restrict__ dW, float* __restrict__ dB) {
+  const int64_t n = (int64_t)OCT * Cin9 + OCT;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nslab; ++k) s += slab[(int64_t)k * n + i];
+  if (i < (int64_t)OCT * Cin9) {
+    const int ocl = (int)(i / Cin9);
+    if (oc_base + ocl < Cout) dW[(int64_t)(oc_base + ocl) * Cin9 + (i % Cin9)] = s;
+  } else if (dB != nullptr) {
+    const int ocl = (int)(i - (int64_t)OCT * Cin9);
+    if (oc_base + ocl < Cout) dB[oc_base + ocl] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NF>
+static int launch_c3(const void* x, const void* xm, int mask_act, const float* w, int64_t so, int64_t si, int tap_rev,
+                     const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act, hipStream_t st) {
+  typedef typename DT<T>::frag_t frag_t;
+  constexpr int CK = 4 * NF * DT<T>::FE;
+  const size_t lds = (size_t)C3_HP * C3_WP * (CK + C3<T>::PADE) * sizeof(T) + (size_t)9 * 4 * NF * 64 * sizeof(frag_t);
+  auto kern = conv3x3_kernel<T, NF>;
+  FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int tiles = B * ((H + C3_TH - 1) / C3_TH) * ((W + C3_TW - 1) / C3_TW);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, (const T*)x, (const T*)xm, mask_act, w, so, si, tap_rev, bias, (T*)y, B,
+                     H, W, Cin, Cout, act);
+  return frl_check_launch("conv3x3");
+}
+
+static int c3_dispatch(const void* x, const void* xm, int mask_act, const float* w, int64_t so, int64_t si, int tap_rev,
+                       const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act, int dtype, hipStream_t st) {
+  if (B <= 0 || H <= 0 || W <= 0) return frl_fail(-2, "conv3x3: empty input");
+  if (dtype == FRL_F32) {
+    if (Cin <= 16) return launch_c3<float, 4>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, st);
+    return launch_c3<float, 8>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, st);
+  } else if (dtype == FRL_BF16) {
+    if (Cin <= 32) return launch_c3<bf16, 1>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, st);
+    return launch_c3<bf16, 2>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, st);
+  }
+  return frl_fail(-2, "conv3x3: bad dtype");
+}
+
+static int c3_wgrad_nwg(int B, int H, int W) {
+  const int tiles = B * ((H + C3_TH - 1) / C3_TH) * ((W + C3_TW - 1) / C3_TW);
+  return tiles < 256 ? tiles : 256;
+}
+
+extern "C" {
+
+// x [B][H][W][Cin], w [Cout][Cin][3][3] f32, bias [Cout] f32 or null, y [B][H][W][Cout]
+int frl_conv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
+                    int dtype, hipStream_t stream) {
+  return c3_dispatch(x, nullptr, 0, w, (int64_t)Cin * 9, 9, 0, bias, y, B, H, W, Cin, Cout, act, dtype, stream);
+}
+
+// dx = conv3x3(dy .* act'(y), w^T flipped)
+int frl_conv3x3_bwd_data(const void* dy, const void* y, int act, const float* w, void* dx, int B, int H, int W, int Cin, int Cout,
+                         int dtype, hipStream_t stream) {
+  return c3_dispatch(dy, act != FRL_ACT_NONE ? y : nullptr, act, w, 9, (int64_t)Cin * 9, 1, nullptr, dx, B, H, W, Cout, Cin,
+                     FRL_ACT_NONE, dtype, stream);
+}
+
+size_t frl_conv3x3_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  (void)Cout;
+  return (size_t)c3_wgrad_nwg(B, H, W) * ((size_t)64 * Cin * 9 + 64) * sizeof(float);
+}
+
+// dw [Cout][Cin][3][3], dbias [Cout] (may be null).  flags bit0: scalar LDS fragment reads (debug A/B check)
+int frl_conv3x3_bwd_weight(const void* dy, const void* y, int act, const void* x, float* dw, float* dbias, int B, int H, int W,
+                           int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, int flags, hipStream_t stream) {
+  if (ws_bytes < frl_conv3x3_bwd_weight_workspace_bytes(B, H, W, Cin, Cout)) return frl_fail(-4, "conv3x3_bwd_weight: workspace too small");
+  const int nwg = c3_wgrad_nwg(B, H, W);
+  const int tiles = B * ((H + C3_TH - 1) / C3_TH) * ((W + C3_TW - 1) / C3_TW);
+  const int tpw = (tiles + nwg - 1) / nwg;
+  const void* ym = act != FRL_ACT_NONE ? y : nullptr;
+  const int64_t slab_n = (int64_t)64 * Cin * 9 + 64;
+  for (int oc_base = 0; oc_base < Cout; oc_base += 64) {
+    if (dtype == FRL_F32) {
+      const size_t lds = ((size_t)128 * (64 + 4) + (size_t)180 * (32 + 4)) * 4;
+      auto kern = conv3x3_wgrad_kernel<float, 2, 2>;
+      FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, stream, (const float*)dy, (const float*)ym, act, (const float*)x, (float*)ws,
+                         B, H, W, Cin, Cout, oc_base, tpw, 0);
+    } else if (dtype == FRL_BF16) {
+      const size_t lds = ((size_t)128 * (64 + 8) + (size_t)180 * (64 + 8)) * 2;
+      auto kern = conv3x3_wgrad_kernel<bf16, 4, 4>;
+      hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, stream, (const bf16*)dy, (const bf16*)ym, act, (const bf16*)x, (float*)ws, B,
+                         H, W, Cin, Cout, oc_base, tpw, (flags & 1) ? 0 : 1);
+    } else return frl_fail(-2, "conv3x3_bwd_weight: bad dtype");
+    hipLaunchKernelGGL(conv3x3_slab_reduce_kernel, dim3((unsigned)((slab_n + 255) / 256)), dim3(256), 0, stream, (const float*)ws, nwg, 64,
+                       Cin * 9, oc_base, Cout, dw, dbias);
+  }
+  return frl_check_launch("conv3x3_bwd_weight");
+}
+
+}  // extern "C"

@@ -1,0 +1,368 @@
+// Fixed-filter stencils of EdgeAwareSmoothingConv2D (frl/models/spatial.py):
+//   * depthwise Sobel/4 gradients  (spatial.py:240-249,295-296)  -> cat[dx,dy] written as one [P][2C] tensor (K5)
+//   * directional bank: 4 orientations x {dilation 1, dilation 3} 3-tap line averages (taps 1/3, zero padding,
+//     spatial.py:224-237,315-325), mixed per channel with the rank-R factored weights
+//     w[k][c] = sum_r softmax_k(A)[k][r] * softmax_r(B)[c][r]  (spatial.py:300-307,324-328), residual = x - smoothed (K9,K10).
+//   The [B,C,R,H,W] slot tensor and the 8 filtered copies of x are never materialised: one thread owns a pixel's
+//   16-byte channel vector, gathers the 17 neighbours it needs (L1/L2 resident) and mixes in registers.
+//   The softmaxed A / B maps are written once (they are the only saved state the backward needs).
+// Roofline: HBM (about 17 cached neighbour reads, ~9 C bytes of compulsory traffic per pixel).
+#include "frl_common.hpp"
+#include "frl_host.hpp"
+
+#define ST_ND 4
+
+__device__ __forceinline__ void st_dir(int i, int& dy, int& dx) {
+  // templates of spatial.py:224-229: E-W, N-S, diagonal (\), anti-diagonal (/)
+  dy = (i == 0) ? 0 : 1;
+  dx = (i == 0) ? 1 : (i == 1) ? 0 : (i == 2) ? 1 : -1;
+}
+
+template <typename T, int V>
+__device__ __forceinline__ bool st_load(const T* __restrict__ X, int b, int y, int x, int H, int W, int C, int c0, float* v) {
+  if (y < 0 || y >= H || x < 0 || x >= W) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = 0.f;
+    return false;
+  }
+  Vec<T>::load(X + ((((int64_t)b * H + y) * W + x) * C + c0), v);
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------ Sobel
+template <typename T, int V>
+__global__ __launch_bounds__(256) void sobel_fwd_kernel(const T* __restrict__ X, T* __restrict__ G, int B, int H, int W, int C) {
+  const int vpr = C / V;
+  const int64_t total = (int64_t)B * H * W * vpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c0 = (int)(i % vpr) * V;
+    const int64_t p = i / vpr;
+    const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+    float gx[V], gy[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { gx[e] = 0.f; gy[e] = 0.f; }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        if (ky == 1 && kx == 1) continue;
+        const float wx = (float)(kx - 1) * (ky == 1 ? 2.f : 1.f) * 0.25f;   // [[-1,0,1],[-2,0,2],[-1,0,1]]/4
+        const float wy = (float)(ky - 1) * (kx == 1 ? 2.f : 1.f) * 0.25f;   // transpose
+        float v[V];
+        if (!st_load<T, V>(X, b, y + ky - 1, x + kx - 1, H, W, C, c0, v)) continue;
+#pragma unroll
+        for (int e = 0; e < V; ++e) { gx[e] = fmaf(wx, v[e], gx[e]); gy[e] = fmaf(wy, v[e], gy[e]); }
+      }
+    Vec<T>::store(G + p * 2 * C + c0, gx);
+    Vec<T>::store(G + p * 2 * C + C + c0, gy);
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void sobel_bwd_kernel(const T* __restrict__ DG, T* __restrict__ DX, int B, int H, int W, int C) {
+  const int vpr = C / V;
+  const int64_t total = (int64_t)B * H * W * vpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c0 = (int)(i % vpr) * V;
+    const int64_t p = i / vpr;
+    const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+    float o[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        if (ky == 1 && kx == 1) continue;
+        // output pixel q = p - (ky-1, kx-1) read x[p] with weight w[ky][kx]
+        const int qy = y - (ky - 1), qx = x - (kx - 1);
+        if (qy < 0 || qy >= H || qx < 0 || qx >= W) continue;
+        const float wx = (float)(kx - 1) * (ky == 1 ? 2.f : 1.f) * 0.25f;
+        const float wy = (float)(ky - 1) * (kx == 1 ? 2.f : 1.f) * 0.25f;
+        const int64_t qp = ((int64_t)b * H + qy) * W + qx;
+        float a[V], c[V];
+        Vec<T>::load(DG + qp * 2 * C + c0, a);
+        Vec<T>::load(DG + qp * 2 * C + C + c0, c);
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = fmaf(wx, a[e], fmaf(wy, c[e], o[e]));
+      }
+    Vec<T>::store(DX + p * C + c0, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ smoothing
+// One workgroup = 256 / TPP pixels; thread (pixel, channel vector).  TPP = power of two >= C / V.
+template <typename T, int V, int R>
+__global__ __launch_bounds__(256) void smooth_fwd_kernel(const T* __restrict__ X, const T* __restrict__ AL, const T* __restrict__ BL,
+                                                         T* __restrict__ SM, T* __restrict__ RES, T* __restrict__ AS, T* __restrict__ BS,
+                                                         int B, int H, int W, int C, int dil, int tpp) {
+  constexpr int K = 2 * ST_ND;
+  const int vpr = C / V;
+  const int ppw = 256 / tpp;
+  const int64_t npix = (int64_t)B * H * W;
+  for (int64_t p = (int64_t)blockIdx.x * ppw + threadIdx.x / tpp; p < npix; p += (int64_t)gridDim.x * ppw) {
+    const int cvi = threadIdx.x % tpp;
+    if (cvi >= vpr) continue;
+    const int c0 = cvi * V;
+    const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+    // softmax over k for each r
+    float A[K][R];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int r = 0; r < R; ++r) A[k][r] = to_f32(AL[p * (K * R) + k * R + r]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float m = A[0][r];
+#pragma unroll
+      for (int k = 1; k < K; ++k) m = fmaxf(m, A[k][r]);
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) { A[k][r] = expf(A[k][r] - m); s += A[k][r]; }
+      const float inv = 1.f / s;
+#pragma unroll
+      for (int k = 0; k < K; ++k) A[k][r] *= inv;
+    }
+    if (cvi == 0) {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int r = 0; r < R; ++r) AS[p * (K * R) + k * R + r] = from_f32<T>(A[k][r]);
+    }
+    // softmax over r for each channel
+    float Bw[V][R];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float m = -3.0e38f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) { Bw[e][r] = to_f32(BL[p * ((int64_t)C * R) + (c0 + e) * R + r]); m = fmaxf(m, Bw[e][r]); }
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) { Bw[e][r] = expf(Bw[e][r] - m); s += Bw[e][r]; }
+      const float inv = 1.f / s;
+#pragma unroll
+      for (int r = 0; r < R; ++r) { Bw[e][r] *= inv; BS[p * ((int64_t)C * R) + (c0 + e) * R + r] = from_f32<T>(Bw[e][r]); }
+    }
+    float ctr[V], sm[V];
+    st_load<T, V>(X, b, y, x, H, W, C, c0, ctr);
+#pragma unroll
+    for (int e = 0; e < V; ++e) sm[e] = 0.f;
+    const float third = 1.f / 3.f;
+#pragma unroll
+    for (int i = 0; i < ST_ND; ++i) {
+      int dy, dx;
+      st_dir(i, dy, dx);
+#pragma unroll
+      for (int sc = 0; sc < 2; ++sc) {
+        const int d = sc ? dil : 1;
+        float a[V], c[V];
+        st_load<T, V>(X, b, y - d * dy, x - d * dx, H, W, C, c0, a);
+        st_load<T, V>(X, b, y + d * dy, x + d * dx, H, W, C, c0, c);
+        const int k = 2 * i + sc;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const float f = third * a[e] + third * ctr[e] + third * c[e];
+          float w = 0.f;
+#pragma unroll
+          for (int r = 0; r < R; ++r) w = fmaf(Bw[e][r], A[k][r], w);
+          sm[e] = fmaf(w, f, sm[e]);
+        }
+      }
+    }
+    float res[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) res[e] = ctr[e] - sm[e];
+    Vec<T>::store(SM + p * C + c0, sm);
+    Vec<T>::store(RES + p * C + c0, res);
+  }
+}
+
+template <typename T, int V, int R>
+__global__ __launch_bounds__(256) void smooth_bwd_kernel(const T* __restrict__ DS, const T* __restrict__ X, const T* __restrict__ AS,
+                                                         const T* __restrict__ BS, T* __restrict__ DX, T* __restrict__ DAL, T* __restrict__ DBL,
+                                                         int B, int H, int W, int C, int dil, int tpp) {
+  constexpr int K = 2 * ST_ND;
+  const int vpr = C / V;
+  const int ppw = 256 / tpp;
+  const int64_t npix = (int64_t)B * H * W;
+  const int64_t nloop = (npix + ppw - 1) / ppw;
+  const float third = 1.f / 3.f;
+  for (int64_t it = blockIdx.x; it < nloop; it += gridDim.x) {
+    const int64_t p = it * ppw + threadIdx.x / tpp;
+    const int cvi = threadIdx.x % tpp;
+    const bool active = (p < npix) && (cvi < vpr);
+    const int64_t pc = p < npix ? p : npix - 1;
+    const int c0 = (cvi < vpr ? cvi : 0) * V;
+    const int x = (int)(pc % W), y = (int)((pc / W) % H), b = (int)(pc / ((int64_t)W * H));
+    float A[K][R], Bw[V][R], ds[V], ctr[V];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int r = 0; r < R; ++r) A[k][r] = to_f32(AS[pc * (K * R) + k * R + r]);
+#pragma unroll
+    for (int e = 0; e < V; ++e)
+#pragma unroll
+      for (int r = 0; r < R; ++r) Bw[e][r] = to_f32(BS[pc * ((int64_t)C * R) + (c0 + e) * R + r]);
+    Vec<T>::load(DS + pc * C + c0, ds);
+    st_load<T, V>(X, b, y, x, H, W, C, c0, ctr);
+    if (!active) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) ds[e] = 0.f;
+    }
+    float slot[V][R], dA[K][R], dx[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      dx[e] = 0.f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) slot[e][r] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int r = 0; r < R; ++r) dA[k][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < ST_ND; ++i) {
+      int dy, dxo;
+      st_dir(i, dy, dxo);
+#pragma unroll
+      for (int sc = 0; sc < 2; ++sc) {
+        const int d = sc ? dil : 1;
+        const int k = 2 * i + sc;
+        float a[V], c[V];
+        st_load<T, V>(X, b, y - d * dy, x - d * dxo, H, W, C, c0, a);
+        st_load<T, V>(X, b, y + d * dy, x + d * dxo, H, W, C, c0, c);
+        float wsum_dummy = 0.f; (void)wsum_dummy;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const float f = third * a[e] + third * ctr[e] + third * c[e];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            slot[e][r] = fmaf(A[k][r], f, slot[e][r]);
+            dA[k][r] = fmaf(ds[e] * Bw[e][r], f, dA[k][r]);
+          }
+          // centre-tap contribution of this filter to d x[p]
+          float w = 0.f;
+#pragma unroll
+          for (int r = 0; r < R; ++r) w = fmaf(Bw[e][r], A[k][r], w);
+          dx[e] = fmaf(third * w, ds[e], dx[e]);
+        }
+        // neighbour contributions: pixels q = p -/+ d*delta whose filter k read x[p]
+#pragma unroll
+        for (int sgn = -1; sgn <= 1; sgn += 2) {
+          const int qy = y + sgn * d * dy, qx = x + sgn * d * dxo;
+          if (qy < 0 || qy >= H || qx < 0 || qx >= W) continue;
+          const int64_t q = ((int64_t)b * H + qy) * W + qx;
+          float dq[V], aq[R];
+          Vec<T>::load(DS + q * C + c0, dq);
+#pragma unroll
+          for (int r = 0; r < R; ++r) aq[r] = to_f32(AS[q * (K * R) + k * R + r]);
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            float w = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) w = fmaf(to_f32(BS[q * ((int64_t)C * R) + (c0 + e) * R + r]), aq[r], w);
+            dx[e] = fmaf(third * w, dq[e], dx[e]);
+          }
+        }
+      }
+    }
+    // d b_logit (softmax over r backward)
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        float dot = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) dot = fmaf(Bw[e][r], ds[e] * slot[e][r], dot);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          DBL[p * ((int64_t)C * R) + (c0 + e) * R + r] = from_f32<T>(Bw[e][r] * (ds[e] * slot[e][r] - dot));
+      }
+      Vec<T>::store(DX + p * C + c0, dx);
+    }
+    // d a_logit: reduce dA over the pixel's channel threads (tpp contiguous lanes), then softmax-over-k backward
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        for (int off = 1; off < tpp; off <<= 1) dA[k][r] += __shfl_xor(dA[k][r], off, 64);
+    if (active && cvi == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) dot = fmaf(A[k][r], dA[k][r], dot);
+#pragma unroll
+        for (int k = 0; k < K; ++k) DAL[p * (K * R) + k * R + r] = from_f32<T>(A[k][r] * (dA[k][r] - dot));
+      }
+    }
+  }
+}
+
+static int st_tpp(int vpr) { int t = 1; while (t < vpr) t <<= 1; return t; }
+static unsigned st_grid(int64_t n) { int64_t g = (n + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1; return (unsigned)g; }
+
+template <typename T, int V>
+static int smooth_dispatch(bool fwd, const void* a0, const void* a1, const void* a2, const void* a3, void* o0, void* o1, void* o2,
+                           void* o3, int B, int H, int W, int C, int R, int dil, hipStream_t st) {
+  const int vpr = C / V, tpp = st_tpp(vpr);
+  if (tpp > 64) return frl_fail(-2, "edge_smooth: too many channels");
+  const int ppw = 256 / tpp;
+  const int64_t npix = (int64_t)B * H * W;
+  int64_t grid = (npix + ppw - 1) / ppw;
+  if (grid > 8192) grid = 8192;
+#define SM_CASE(RR)                                                                                                     \
+  if (R == RR) {                                                                                                        \
+    if (fwd) hipLaunchKernelGGL((smooth_fwd_kernel<T, V, RR>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)a0, (const T*)a1, \
+                                (const T*)a2, (T*)o0, (T*)o1, (T*)o2, (T*)o3, B, H, W, C, dil, tpp);                     \
+    else hipLaunchKernelGGL((smooth_bwd_kernel<T, V, RR>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)a0, (const T*)a1,      \
+                            (const T*)a2, (const T*)a3, (T*)o0, (T*)o1, (T*)o2, B, H, W, C, dil, tpp);                   \
+    return frl_check_launch("edge_smooth_stencil");                                                                     \
+  }
+  SM_CASE(1) SM_CASE(2) SM_CASE(4)
+#undef SM_CASE
+  return frl_fail(-2, "edge_smooth: rank must be 1, 2 or 4");
+}
+
+extern "C" {
+
+// x [B][H][W][C] -> g [B][H][W][2C] = cat[sobel_x(x), sobel_y(x)]
+int frl_sobel_fwd(const void* x, void* g, int B, int H, int W, int C, int dtype, hipStream_t stream) {
+  if (dtype == FRL_F32 && C % 4 == 0)
+    hipLaunchKernelGGL((sobel_fwd_kernel<float, 4>), dim3(st_grid((int64_t)B * H * W * (C / 4))), dim3(256), 0, stream, (const float*)x, (float*)g, B, H, W, C);
+  else if (dtype == FRL_BF16 && C % 8 == 0)
+    hipLaunchKernelGGL((sobel_fwd_kernel<bf16, 8>), dim3(st_grid((int64_t)B * H * W * (C / 8))), dim3(256), 0, stream, (const bf16*)x, (bf16*)g, B, H, W, C);
+  else return frl_fail(-2, "sobel: C must be a multiple of 8 (bf16) / 4 (f32)");
+  return frl_check_launch("sobel_fwd");
+}
+
+int frl_sobel_bwd(const void* dg, void* dx, int B, int H, int W, int C, int dtype, hipStream_t stream) {
+  if (dtype == FRL_F32 && C % 4 == 0)
+    hipLaunchKernelGGL((sobel_bwd_kernel<float, 4>), dim3(st_grid((int64_t)B * H * W * (C / 4))), dim3(256), 0, stream, (const float*)dg, (float*)dx, B, H, W, C);
+  else if (dtype == FRL_BF16 && C % 8 == 0)
+    hipLaunchKernelGGL((sobel_bwd_kernel<bf16, 8>), dim3(st_grid((int64_t)B * H * W * (C / 8))), dim3(256), 0, stream, (const bf16*)dg, (bf16*)dx, B, H, W, C);
+  else return frl_fail(-2, "sobel: C must be a multiple of 8 (bf16) / 4 (f32)");
+  return frl_check_launch("sobel_bwd");
+}
+
+// x [P][C]; a_logit [P][8*R] (channel k*R+r); b_logit [P][C*R] (channel c*R+r).
+// Outputs: smoothed, residual [P][C]; a_soft, b_soft (softmaxed maps, saved for backward).  4 directions x 2 scales.
+int frl_edge_smooth_stencil_fwd(const void* x, const void* a_logit, const void* b_logit, void* smoothed, void* residual, void* a_soft,
+                                void* b_soft, int B, int H, int W, int C, int R, int coarse_dilation, int dtype, hipStream_t stream) {
+  if (dtype == FRL_F32 && C % 4 == 0)
+    return smooth_dispatch<float, 4>(true, x, a_logit, b_logit, nullptr, smoothed, residual, a_soft, b_soft, B, H, W, C, R, coarse_dilation, stream);
+  if (dtype == FRL_BF16 && C % 8 == 0)
+    return smooth_dispatch<bf16, 8>(true, x, a_logit, b_logit, nullptr, smoothed, residual, a_soft, b_soft, B, H, W, C, R, coarse_dilation, stream);
+  return frl_fail(-2, "edge_smooth: C must be a multiple of 8 (bf16) / 4 (f32)");
+}
+
+// d_smoothed -> dx (stencil part only), d a_logit, d b_logit
+int frl_edge_smooth_stencil_bwd(const void* d_smoothed, const void* x, const void* a_soft, const void* b_soft, void* dx, void* da_logit,
+                                void* db_logit, int B, int H, int W, int C, int R, int coarse_dilation, int dtype, hipStream_t stream) {
+  if (dtype == FRL_F32 && C % 4 == 0)
+    return smooth_dispatch<float, 4>(false, d_smoothed, x, a_soft, b_soft, dx, da_logit, db_logit, nullptr, B, H, W, C, R, coarse_dilation, stream);
+  if (dtype == FRL_BF16 && C % 8 == 0)
+    return smooth_dispatch<bf16, 8>(false, d_smoothed, x, a_soft, b_soft, dx, da_logit, db_logit, nullptr, B, H, W, C, R, coarse_dilation, stream);
+  return frl_fail(-2, "edge_smooth: C must be a multiple of 8 (bf16) / 4 (f32)");
+}
+
+}  // extern "C"

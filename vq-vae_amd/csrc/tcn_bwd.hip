@@ -1,0 +1,266 @@
+// Fused GatedResidualBlock backward, main kernel (frl/models/tcn.py:78-111 differentiated by hand).
+// Recomputes conv -> GroupNorm -> gate from x (nothing but x is saved by the forward), then per pixel:
+//   dg = dy (relu(n) - res) ; dgpre = dg g (1-g) ; dres = dy (1-g) ; dn = dy g [n>0] + Wg^T dgpre
+//   GroupNorm backward over (group channels x T) in-lane ; dconv = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat))
+// Outputs feed the MFMA weight-gradient kernels (pw_wgrad.hip): dconv (3 temporal taps against x), dgpre against the
+// normalised features `normed`, dres against x (projection only); d gamma / d beta are reduced in fixed order.
+// dx itself is produced by frl_tcn_block_bwd_data (conv^T over dconv + residual path).
+#include "tcn_common.hpp"
+#include "frl_host.hpp"
+
+template <typename T, int NFI, int MBO>
+__global__ __launch_bounds__(256) void tcn_block_bwd_kernel(const T* __restrict__ X, const T* __restrict__ DY, const float* __restrict__ Wc,
+                                                            const float* __restrict__ bc, const float* __restrict__ gn_w,
+                                                            const float* __restrict__ gn_b, const float* __restrict__ Wg,
+                                                            const float* __restrict__ bg, const float* __restrict__ Wp,
+                                                            const float* __restrict__ bp, T* DCONV, T* __restrict__ DGPRE,
+                                                            T* __restrict__ NORMED, T* __restrict__ DRES, float* __restrict__ slab, TcnArgs a) {
+  typedef typename DT<T>::frag_t frag_t;
+  constexpr int FE = DT<T>::FE;
+  constexpr int Q = 4 * MBO;
+  constexpr int NFO = Q / FE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  frag_t* wl_conv = reinterpret_cast<frag_t*>(smem);                // [3][MBO][NFI][64]
+  frag_t* wl_gate = wl_conv + 3 * MBO * NFI * 64;                   // [MBO][NFO][64]
+  frag_t* wl_gateT = wl_gate + MBO * NFO * 64;                      // [MBO][NFO][64]  (Wg^T)
+  frag_t* wl_proj = wl_gateT + MBO * NFO * 64;                      // [MBO][NFI][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, kc = lane >> 4;
+  for (int k = 0; k < 3; ++k)
+    pack_weights_lds<T, NFI>(wl_conv + k * MBO * NFI * 64, Wc + k, a.Cout, a.Cin, MBO, (int64_t)a.Cin * 3, 3, tid, 256);
+  pack_weights_lds<T, NFO>(wl_gate, Wg, a.Cout, a.Cout, MBO, a.Cout, 1, tid, 256);
+  pack_weights_lds<T, NFO>(wl_gateT, Wg, a.Cout, a.Cout, MBO, 1, a.Cout, tid, 256);
+  if (Wp != nullptr) pack_weights_lds<T, NFI>(wl_proj, Wp, a.Cout, a.Cin, MBO, a.Cin, 1, tid, 256);
+  __syncthreads();
+
+  const bool fast_in = (a.Cin == 4 * NFI * FE), fast_out = (a.Cout == 4 * Q);
+  const int cg = a.Cout / a.G;
+  const float inv_n = 1.f / ((float)cg * (float)a.Tn);
+  float dgam[Q], dbet[Q];
+#pragma unroll
+  for (int j = 0; j < Q; ++j) { dgam[j] = 0.f; dbet[j] = 0.f; }
+  float gw[Q], gb[Q], gbias[Q], cb[Q];
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+    const int c = Q * kc + j;
+    const bool ok = c < a.Cout;
+    gw[j] = ok ? gn_w[c] : 0.f;
+    gb[j] = ok ? gn_b[c] : 0.f;
+    gbias[j] = ok ? bg[c] : 0.f;
+    cb[j] = ok ? bc[c] : 0.f;
+  }
+
+  const int64_t ntile = (a.npix + 15) >> 4;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
+    int64_t pidx = tile * 16 + px;
+    const bool valid = pidx < a.npix;
+    const float vf = valid ? 1.f : 0.f;
+    if (!valid) pidx = a.npix - 1;
+    const int64_t b = pidx / a.HW, hw = pidx % a.HW;
+    const int64_t row0 = b * a.Tn * a.HW + hw;
+    float mean[Q], rstd[Q];
+    tcn_stats<T, NFI, MBO>(mean, rstd, X, row0, a, kc, fast_in, wl_conv, bc, lane);
+#pragma unroll
+    for (int j = 0; j < Q; ++j) mean[j] -= cb[j];       // fold the conv bias: xhat = (acc - mean) * rstd
+    float S1[Q], S2[Q];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) { S1[j] = 0.f; S2[j] = 0.f; }
+    // ---------------- pass 2: dn, side outputs, group sums ----------------
+    for (int t = 0; t < a.Tn; ++t) {
+      const int64_t row = row0 + (int64_t)t * a.HW;
+      f32x4 acc[MBO];
+#pragma unroll
+      for (int m = 0; m < MBO; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      tconv_at<T, NFI, MBO>(acc, X, row0, a, t, a.Cin, kc, fast_in, wl_conv, lane);
+      float xh[Q], n[Q];
+#pragma unroll
+      for (int j = 0; j < Q; ++j) { xh[j] = (acc[j >> 2][j & 3] - mean[j]) * rstd[j]; n[j] = fmaf(xh[j], gw[j], gb[j]); }
+      LQTile<T, NFO> nt;
+      acc_to_tile<T, MBO>(nt, n);
+      f32x4 gacc[MBO];
+#pragma unroll
+      for (int m = 0; m < MBO; ++m) gacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      pw_at<T, NFO, MBO>(gacc, nt, wl_gate, lane);
+      LQTile<T, NFI> xt;
+      lq_load<T, NFI>(xt, X, row, a.Cin, kc, fast_in);
+      float res[Q];
+      if (Wp != nullptr) {
+        f32x4 pacc[MBO];
+#pragma unroll
+        for (int m = 0; m < MBO; ++m) pacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        pw_at<T, NFI, MBO>(pacc, xt, wl_proj, lane);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) { const int c = Q * kc + j; res[j] = pacc[j >> 2][j & 3] + (c < a.Cout ? bp[c] : 0.f); }
+      } else {
+        if constexpr (NFI * FE == Q) {
+#pragma unroll
+          for (int j = 0; j < Q; ++j) res[j] = lq_get<T, NFI>(xt, j / FE, j % FE);
+        } else {
+#pragma unroll
+          for (int j = 0; j < Q; ++j) res[j] = 0.f;
+        }
+      }
+      LQTile<T, NFO> dyt;
+      lq_load<T, NFO>(dyt, DY, row, a.Cout, kc, fast_out);
+      float dgp[Q], dr[Q], dn[Q];
+#pragma unroll
+      for (int j = 0; j < Q; ++j) {
+        const float dy = lq_get<T, NFO>(dyt, j / FE, j % FE) * vf;
+        const float g = 1.f / (1.f + expf(-(gacc[j >> 2][j & 3] + gbias[j])));
+        const float o = n[j] > 0.f ? n[j] : 0.f;
+        dgp[j] = dy * (o - res[j]) * g * (1.f - g);
+        dr[j] = dy * (1.f - g);
+        dn[j] = n[j] > 0.f ? dy * g : 0.f;
+      }
+      LQTile<T, NFO> gt;
+      acc_to_tile<T, MBO>(gt, dgp);
+      f32x4 bacc[MBO];
+#pragma unroll
+      for (int m = 0; m < MBO; ++m) bacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      pw_at<T, NFO, MBO>(bacc, gt, wl_gateT, lane);
+#pragma unroll
+      for (int j = 0; j < Q; ++j) {
+        dn[j] += bacc[j >> 2][j & 3];
+        const float dxh = dn[j] * gw[j];
+        S1[j] += dxh;
+        S2[j] = fmaf(dxh, xh[j], S2[j]);
+        dgam[j] = fmaf(dn[j], xh[j], dgam[j]);
+        dbet[j] += dn[j];
+      }
+      if (valid) {
+        lq_store<T, NFO>(nt, NORMED, row, a.Cout, kc, fast_out);
+        lq_store<T, NFO>(gt, DGPRE, row, a.Cout, kc, fast_out);
+        LQTile<T, NFO> tt;
+        acc_to_tile<T, MBO>(tt, dr);
+        lq_store<T, NFO>(tt, DRES, row, a.Cout, kc, fast_out);
+        acc_to_tile<T, MBO>(tt, dn);
+        lq_store<T, NFO>(tt, DCONV, row, a.Cout, kc, fast_out);      // temporary: dn, rewritten below
+      }
+    }
+    float m1[Q], m2[Q];
+    group_combine<Q>(m1, S1, cg);
+    group_combine<Q>(m2, S2, cg);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own dn stores have landed before they are re-read
+    // ---------------- pass 3: GroupNorm backward -> dconv ----------------
+    for (int t = 0; t < a.Tn; ++t) {
+      const int64_t row = row0 + (int64_t)t * a.HW;
+      f32x4 acc[MBO];
+#pragma unroll
+      for (int m = 0; m < MBO; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      tconv_at<T, NFI, MBO>(acc, X, row0, a, t, a.Cin, kc, fast_in, wl_conv, lane);
+      LQTile<T, NFO> dnt;
+      lq_load<T, NFO>(dnt, DCONV, row, a.Cout, kc, fast_out);
+      float dc[Q];
+#pragma unroll
+      for (int j = 0; j < Q; ++j) {
+        const float xh = (acc[j >> 2][j & 3] - mean[j]) * rstd[j];
+        const float dxh = lq_get<T, NFO>(dnt, j / FE, j % FE) * gw[j];
+        dc[j] = rstd[j] * (dxh - m1[j] * inv_n - xh * m2[j] * inv_n);
+      }
+      if (valid) {
+        LQTile<T, NFO> tt;
+        acc_to_tile<T, MBO>(tt, dc);
+        lq_store<T, NFO>(tt, DCONV, row, a.Cout, kc, fast_out);
+      }
+    }
+  }
+  // ---------------- d gamma / d beta: reduce over the 16 pixel lanes, the 4 waves, write the workgroup slab ----------------
+  float* red = reinterpret_cast<float*>(smem);            // reuse LDS (weights no longer needed)
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) { dgam[j] += __shfl_xor(dgam[j], off, 64); dbet[j] += __shfl_xor(dbet[j], off, 64); }
+    if (px == 0) {
+      red[(wave * 2 + 0) * 4 * Q + Q * kc + j] = dgam[j];
+      red[(wave * 2 + 1) * 4 * Q + Q * kc + j] = dbet[j];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * a.Cout; i += 256) {
+    const int which = i / a.Cout, c = i % a.Cout;
+    float s = 0.f;
+    for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * 4 * Q + c];
+    slab[(int64_t)blockIdx.x * 2 * a.Cout + i] = s;
+  }
+}
+
+static unsigned tcn_bwd_grid(int64_t npix) {
+  int64_t g = ((npix + 15) / 16 + 3) / 4;
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+// out[i] = sum_k slab[k][i]
+__global__ void tcn_slab_reduce_kernel(const float* __restrict__ slab, int nslab, int n, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * n) return;
+  float s = 0.f;
+  for (int k = 0; k < nslab; ++k) s += slab[(int64_t)k * 2 * n + i];
+  if (i < n) dgamma[i] = s; else dbeta[i - n] = s;
+}
+
+template <typename T, int NFI, int MBO>
+static int launch_tcn_bwd(const void* x, const void* dy, const float* wc, const float* bc, const float* gw, const float* gb, const float* wg,
+                          const float* bg, const float* wp, const float* bp, void* dconv, void* dgpre, void* normed, void* dres,
+                          float* dgamma, float* dbeta, float* ws, const TcnArgs& a, hipStream_t st) {
+  typedef typename DT<T>::frag_t frag_t;
+  constexpr int NFO = 4 * MBO / DT<T>::FE;
+  size_t lds = (size_t)(3 * MBO * NFI + 2 * MBO * NFO + (wp ? MBO * NFI : 0)) * 64 * sizeof(frag_t);
+  const size_t red = (size_t)8 * 16 * MBO * sizeof(float);
+  if (lds < red) lds = red;
+  if (lds > 160 * 1024) return frl_fail(-3, "tcn_block_bwd: weights exceed LDS");
+  auto kern = tcn_block_bwd_kernel<T, NFI, MBO>;
+  if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const unsigned grid = tcn_bwd_grid(a.npix);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, (const T*)x, (const T*)dy, wc, bc, gw, gb, wg, bg, wp, bp, (T*)dconv, (T*)dgpre,
+                     (T*)normed, (T*)dres, ws, a);
+  hipLaunchKernelGGL(tcn_slab_reduce_kernel, dim3((2 * a.Cout + 255) / 256), dim3(256), 0, st, (const float*)ws, (int)grid, a.Cout, dgamma, dbeta);
+  return frl_check_launch("tcn_block_bwd");
+}
+
+static int pad_class_b(int C, int dtype) {
+  if (dtype == FRL_F32) return C <= 16 ? 16 : C <= 32 ? 32 : C <= 64 ? 64 : C <= 128 ? 128 : -1;
+  return C <= 32 ? 32 : C <= 64 ? 64 : C <= 128 ? 128 : -1;
+}
+int frl_tcn_check(int Cin, int Cout, int G, int dtype);
+
+#define TCN_SWITCH_F32(PI, PO, CALL)                                   \
+  switch ((PI) * 1000 + (PO)) {                                        \
+    case 16016: { CALL(float, 4, 1) } case 16032: { CALL(float, 4, 2) } case 16064: { CALL(float, 4, 4) } case 16128: { CALL(float, 4, 8) } \
+    case 32016: { CALL(float, 8, 1) } case 32032: { CALL(float, 8, 2) } case 32064: { CALL(float, 8, 4) } case 32128: { CALL(float, 8, 8) } \
+    case 64016: { CALL(float, 16, 1) } case 64032: { CALL(float, 16, 2) } case 64064: { CALL(float, 16, 4) } case 64128: { CALL(float, 16, 8) } \
+    case 128016: { CALL(float, 32, 1) } case 128032: { CALL(float, 32, 2) } case 128064: { CALL(float, 32, 4) } case 128128: { CALL(float, 32, 8) } \
+    default: break; }
+#define TCN_SWITCH_BF16(PI, PO, CALL)                                  \
+  switch ((PI) * 1000 + (PO)) {                                        \
+    case 32032: { CALL(bf16, 1, 2) } case 32064: { CALL(bf16, 1, 4) } case 32128: { CALL(bf16, 1, 8) }     \
+    case 64032: { CALL(bf16, 2, 2) } case 64064: { CALL(bf16, 2, 4) } case 64128: { CALL(bf16, 2, 8) }     \
+    case 128032: { CALL(bf16, 4, 2) } case 128064: { CALL(bf16, 4, 4) } case 128128: { CALL(bf16, 4, 8) }  \
+    default: break; }
+
+extern "C" {
+
+size_t frl_tcn_block_bwd_workspace_bytes(int64_t npix, int Cout) { return (size_t)tcn_bwd_grid(npix) * 2 * Cout * sizeof(float); }
+
+// Side outputs (all [B][T][HW][Cout], dtype): dconv, dgpre, normed, dres; dgamma/dbeta [Cout] f32.
+int frl_tcn_block_bwd(const void* x, const void* dy, const float* conv_w, const float* conv_b, const float* gn_w, const float* gn_b,
+                      const float* gate_w, const float* gate_b, const float* proj_w, const float* proj_b, void* dconv, void* dgpre,
+                      void* normed, void* dres, float* dgamma, float* dbeta, int64_t npix, int HW, int T, int Cin, int Cout,
+                      int dilation, int G, float eps, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (npix <= 0 || T <= 0) return frl_fail(-2, "tcn_block_bwd: empty input");
+  if (ws_bytes < frl_tcn_block_bwd_workspace_bytes(npix, Cout)) return frl_fail(-4, "tcn_block_bwd: workspace too small");
+  if (proj_w == nullptr && Cin != Cout) return frl_fail(-2, "tcn_block_bwd: identity residual needs Cin == Cout");
+  int rc = frl_tcn_check(Cin, Cout, G, dtype);
+  if (rc) return rc;
+  TcnArgs a{npix, HW, T, dilation, Cin, Cout, G, eps};
+  const int pi = pad_class_b(Cin, dtype), po = pad_class_b(Cout, dtype);
+#define CALL(TT, NFI, MBO) return launch_tcn_bwd<TT, NFI, MBO>(x, dy, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, dconv, dgpre, normed, dres, dgamma, dbeta, (float*)ws, a, stream);
+  if (dtype == FRL_F32) TCN_SWITCH_F32(pi, po, CALL)
+  else if (dtype == FRL_BF16) TCN_SWITCH_BF16(pi, po, CALL)
+#undef CALL
+  return frl_fail(-2, "tcn_block_bwd: unsupported dtype / widths");
+}
+
+}  // extern "C"

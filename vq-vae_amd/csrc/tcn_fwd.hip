@@ -1,0 +1,257 @@
+// Fused GatedResidualBlock forward (frl/models/tcn.py:78-111), one launch per block:
+//   res = proj(x) | x ;  c = conv1d_k3_dil(x) + b ;  n = GroupNorm_(8ch x T per pixel)(c) ;  g = sigmoid(Wg n + bg) ;
+//   y = g * relu(n) + (1 - g) * res
+// plus the generic 3-tap temporal convolution used by the backward pass (dx = conv^T(dconv) [+ residual]).
+// MFMA work per (pixel, t): 3 taps x Cin x Cout (computed twice: statistics pass + apply pass) + Cout x Cout gate.
+// HBM traffic: x read (taps hit L1/L2), y written once -- the GroupNorm / gate / blend intermediates never leave the CU.
+#include "tcn_common.hpp"
+#include "frl_host.hpp"
+
+template <typename T, int NFI, int MBO>
+__global__ __launch_bounds__(256) void tcn_block_fwd_kernel(const T* __restrict__ X, const float* __restrict__ Wc, const float* __restrict__ bc,
+                                                            const float* __restrict__ gn_w, const float* __restrict__ gn_b,
+                                                            const float* __restrict__ Wg, const float* __restrict__ bg,
+                                                            const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                            T* __restrict__ Y, TcnArgs a) {
+  typedef typename DT<T>::frag_t frag_t;
+  constexpr int FE = DT<T>::FE;
+  constexpr int Q = 4 * MBO;            // output channels per lane quarter
+  constexpr int NFO = Q / FE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  frag_t* wl_conv = reinterpret_cast<frag_t*>(smem);                // [3][MBO][NFI][64]
+  frag_t* wl_gate = wl_conv + 3 * MBO * NFI * 64;                   // [MBO][NFO][64]
+  frag_t* wl_proj = wl_gate + MBO * NFO * 64;                       // [MBO][NFI][64] (only if Wp)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, kc = lane >> 4;
+  for (int k = 0; k < 3; ++k)
+    pack_weights_lds<T, NFI>(wl_conv + k * MBO * NFI * 64, Wc + k, a.Cout, a.Cin, MBO, (int64_t)a.Cin * 3, 3, tid, 256);
+  pack_weights_lds<T, NFO>(wl_gate, Wg, a.Cout, a.Cout, MBO, a.Cout, 1, tid, 256);
+  if (Wp != nullptr) pack_weights_lds<T, NFI>(wl_proj, Wp, a.Cout, a.Cin, MBO, a.Cin, 1, tid, 256);
+  __syncthreads();
+
+  const bool fast_in = (a.Cin == 4 * NFI * FE), fast_out = (a.Cout == 4 * Q);
+  const int64_t ntile = (a.npix + 15) >> 4;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
+    int64_t pidx = tile * 16 + px;
+    const bool valid = pidx < a.npix;
+    if (!valid) pidx = a.npix - 1;
+    const int64_t b = pidx / a.HW, hw = pidx % a.HW;
+    const int64_t row0 = b * a.Tn * a.HW + hw;
+    float mean[Q], rstd[Q];
+    tcn_stats<T, NFI, MBO>(mean, rstd, X, row0, a, kc, fast_in, wl_conv, bc, lane);
+    float cb[Q], gw[Q], gb[Q], gbias[Q], pb[Q];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+      const int c = Q * kc + j;
+      const bool ok = c < a.Cout;
+      cb[j] = ok ? bc[c] : 0.f;
+      gw[j] = ok ? gn_w[c] : 0.f;
+      gb[j] = ok ? gn_b[c] : 0.f;
+      gbias[j] = ok ? bg[c] : 0.f;
+      pb[j] = (ok && Wp != nullptr) ? bp[c] : 0.f;
+    }
+    for (int t = 0; t < a.Tn; ++t) {
+      f32x4 acc[MBO];
+#pragma unroll
+      for (int m = 0; m < MBO; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      tconv_at<T, NFI, MBO>(acc, X, row0, a, t, a.Cin, kc, fast_in, wl_conv, lane);
+      float n[Q];
+#pragma unroll
+      for (int j = 0; j < Q; ++j) n[j] = fmaf((acc[j >> 2][j & 3] + cb[j] - mean[j]) * rstd[j], gw[j], gb[j]);
+      LQTile<T, NFO> nt;
+      acc_to_tile<T, MBO>(nt, n);
+      f32x4 gacc[MBO];
+#pragma unroll
+      for (int m = 0; m < MBO; ++m) gacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      pw_at<T, NFO, MBO>(gacc, nt, wl_gate, lane);
+      // residual
+      LQTile<T, NFI> xt;
+      lq_load<T, NFI>(xt, X, row0 + (int64_t)t * a.HW, a.Cin, kc, fast_in);
+      float res[Q];
+      if (Wp != nullptr) {
+        f32x4 pacc[MBO];
+#pragma unroll
+        for (int m = 0; m < MBO; ++m) pacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        pw_at<T, NFI, MBO>(pacc, xt, wl_proj, lane);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) res[j] = pacc[j >> 2][j & 3] + pb[j];
+      } else {
+        // identity: Cin == Cout, same padded width -> x tile is already the lane-quarter image
+        if constexpr (NFI * FE == Q) {
+#pragma unroll
+          for (int j = 0; j < Q; ++j) res[j] = lq_get<T, NFI>(xt, j / FE, j % FE);
+        } else {
+#pragma unroll
+          for (int j = 0; j < Q; ++j) res[j] = 0.f;
+        }
+      }
+      float y[Q];
+#pragma unroll
+      for (int j = 0; j < Q; ++j) {
+        const float g = 1.f / (1.f + expf(-(gacc[j >> 2][j & 3] + gbias[j])));
+        const float o = n[j] > 0.f ? n[j] : 0.f;
+        y[j] = g * o + (1.f - g) * res[j];
+      }
+      if (valid) {
+        LQTile<T, NFO> yt;
+        acc_to_tile<T, MBO>(yt, y);
+        lq_store<T, NFO>(yt, Y, row0 + (int64_t)t * a.HW, a.Cout, kc, fast_out);
+      }
+    }
+  }
+}
+
+// Generic 3-tap temporal convolution with optional extra pointwise term:
+//   Y[t] = sum_k W_k X[t + (k-1) dil]  (+ R[t] if add_r)  (+ Wp R2[t])
+// Weff_k[o][i] = W[o * so + i * si + (rev ? 2 - k : k)]; used as conv^T in the TCN backward.
+template <typename T, int NFI, int MBO, int NFP>
+__global__ __launch_bounds__(256) void tconv3_kernel(const T* __restrict__ X, const float* __restrict__ W, int64_t so, int64_t si, int rev,
+                                                     const T* __restrict__ R, const T* __restrict__ R2, const float* __restrict__ Wp,
+                                                     int64_t pso, int64_t psi, int Cp, T* __restrict__ Y, TcnArgs a) {
+  typedef typename DT<T>::frag_t frag_t;
+  constexpr int FE = DT<T>::FE;
+  constexpr int Q = 4 * MBO, NFO = Q / FE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  frag_t* wl_conv = reinterpret_cast<frag_t*>(smem);
+  frag_t* wl_p = wl_conv + 3 * MBO * NFI * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, kc = lane >> 4;
+  for (int k = 0; k < 3; ++k)
+    pack_weights_lds<T, NFI>(wl_conv + k * MBO * NFI * 64, W + (rev ? 2 - k : k), a.Cout, a.Cin, MBO, so, si, tid, 256);
+  if (Wp != nullptr) pack_weights_lds<T, NFP>(wl_p, Wp, a.Cout, Cp, MBO, pso, psi, tid, 256);
+  __syncthreads();
+  const bool fast_in = (a.Cin == 4 * NFI * FE), fast_out = (a.Cout == 4 * Q), fast_p = (Cp == 4 * NFP * FE);
+  const int64_t ntile = (a.npix + 15) >> 4;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
+    int64_t pidx = tile * 16 + px;
+    const bool valid = pidx < a.npix;
+    if (!valid) pidx = a.npix - 1;
+    const int64_t b = pidx / a.HW, hw = pidx % a.HW;
+    const int64_t row0 = b * a.Tn * a.HW + hw;
+    for (int t = 0; t < a.Tn; ++t) {
+      f32x4 acc[MBO];
+#pragma unroll
+      for (int m = 0; m < MBO; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      tconv_at<T, NFI, MBO>(acc, X, row0, a, t, a.Cin, kc, fast_in, wl_conv, lane);
+      if (Wp != nullptr) {
+        LQTile<T, NFP> rt;
+        lq_load<T, NFP>(rt, R2, row0 + (int64_t)t * a.HW, Cp, kc, fast_p);
+        pw_at<T, NFP, MBO>(acc, rt, wl_p, lane);
+      }
+      float y[Q];
+#pragma unroll
+      for (int j = 0; j < Q; ++j) y[j] = acc[j >> 2][j & 3];
+      if (R != nullptr) {
+        LQTile<T, NFO> rt;
+        lq_load<T, NFO>(rt, R, row0 + (int64_t)t * a.HW, a.Cout, kc, fast_out);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) y[j] += lq_get<T, NFO>(rt, j / FE, j % FE);
+      }
+      if (valid) {
+        LQTile<T, NFO> yt;
+        acc_to_tile<T, MBO>(yt, y);
+        lq_store<T, NFO>(yt, Y, row0 + (int64_t)t * a.HW, a.Cout, kc, fast_out);
+      }
+    }
+  }
+}
+
+static unsigned tcn_grid(int64_t npix) {
+  int64_t g = ((npix + 15) / 16 + 3) / 4;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+template <typename T, int NFI, int MBO>
+static int launch_tcn_fwd(const void* x, const float* wc, const float* bc, const float* gw, const float* gb, const float* wg,
+                          const float* bg, const float* wp, const float* bp, void* y, const TcnArgs& a, hipStream_t st) {
+  typedef typename DT<T>::frag_t frag_t;
+  constexpr int NFO = 4 * MBO / DT<T>::FE;
+  const size_t lds = (size_t)(3 * MBO * NFI + MBO * NFO + (wp ? MBO * NFI : 0)) * 64 * sizeof(frag_t);
+  if (lds > 160 * 1024) return frl_fail(-3, "tcn_block_fwd: weights exceed LDS");
+  auto kern = tcn_block_fwd_kernel<T, NFI, MBO>;
+  if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(tcn_grid(a.npix)), dim3(256), lds, st, (const T*)x, wc, bc, gw, gb, wg, bg, wp, bp, (T*)y, a);
+  return frl_check_launch("tcn_block_fwd");
+}
+
+template <typename T, int NFI, int MBO, int NFP>
+static int launch_tconv3(const void* x, const float* w, int64_t so, int64_t si, int rev, const void* r, const void* r2,
+                         const float* wp, int64_t pso, int64_t psi, int Cp, void* y, const TcnArgs& a, hipStream_t st) {
+  typedef typename DT<T>::frag_t frag_t;
+  const size_t lds = (size_t)(3 * MBO * NFI + (wp ? MBO * NFP : 0)) * 64 * sizeof(frag_t);
+  if (lds > 160 * 1024) return frl_fail(-3, "tconv3: weights exceed LDS");
+  auto kern = tconv3_kernel<T, NFI, MBO, NFP>;
+  if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(tcn_grid(a.npix)), dim3(256), lds, st, (const T*)x, w, so, si, rev, (const T*)r, (const T*)r2, wp, pso,
+                     psi, Cp, (T*)y, a);
+  return frl_check_launch("tconv3");
+}
+
+// padded-width class: f32 -> {16,32,64,128} ; bf16 -> {32,64,128}
+static int pad_class(int C, int dtype) {
+  if (dtype == FRL_F32) return C <= 16 ? 16 : C <= 32 ? 32 : C <= 64 ? 64 : C <= 128 ? 128 : -1;
+  return C <= 32 ? 32 : C <= 64 ? 64 : C <= 128 ? 128 : -1;
+}
+
+int frl_tcn_check(int Cin, int Cout, int G, int dtype) {
+  const int pi = pad_class(Cin, dtype), po = pad_class(Cout, dtype);
+  if (pi < 0 || po < 0) return frl_fail(-2, "tcn: channel counts above 128 unsupported");
+  if (G <= 0 || Cout % G != 0) return frl_fail(-2, "tcn: Cout must be divisible by num_groups");
+  const int cg = Cout / G;
+  if ((po / 4) % cg != 0) return frl_fail(-2, "tcn: GroupNorm group must fit inside a lane quarter (Cout_pad/4 % (Cout/G) == 0)");
+  return 0;
+}
+
+#define TCN_SWITCH_F32(PI, PO, CALL)                                   \
+  switch ((PI) * 1000 + (PO)) {                                        \
+    case 16016: { CALL(float, 4, 1) } case 16032: { CALL(float, 4, 2) } case 16064: { CALL(float, 4, 4) } case 16128: { CALL(float, 4, 8) } \
+    case 32016: { CALL(float, 8, 1) } case 32032: { CALL(float, 8, 2) } case 32064: { CALL(float, 8, 4) } case 32128: { CALL(float, 8, 8) } \
+    case 64016: { CALL(float, 16, 1) } case 64032: { CALL(float, 16, 2) } case 64064: { CALL(float, 16, 4) } case 64128: { CALL(float, 16, 8) } \
+    case 128016: { CALL(float, 32, 1) } case 128032: { CALL(float, 32, 2) } case 128064: { CALL(float, 32, 4) } case 128128: { CALL(float, 32, 8) } \
+    default: break; }
+#define TCN_SWITCH_BF16(PI, PO, CALL)                                  \
+  switch ((PI) * 1000 + (PO)) {                                        \
+    case 32032: { CALL(bf16, 1, 2) } case 32064: { CALL(bf16, 1, 4) } case 32128: { CALL(bf16, 1, 8) }     \
+    case 64032: { CALL(bf16, 2, 2) } case 64064: { CALL(bf16, 2, 4) } case 64128: { CALL(bf16, 2, 8) }     \
+    case 128032: { CALL(bf16, 4, 2) } case 128064: { CALL(bf16, 4, 4) } case 128128: { CALL(bf16, 4, 8) }  \
+    default: break; }
+
+extern "C" {
+
+// x [B][T][HW][Cin] -> y [B][T][HW][Cout].  conv_w [Cout][Cin][3], gate_w [Cout][Cout], proj_w [Cout][Cin] or null
+// (null <=> identity residual, requires Cin == Cout).  npix = B*HW.
+int frl_tcn_block_fwd(const void* x, const float* conv_w, const float* conv_b, const float* gn_w, const float* gn_b,
+                      const float* gate_w, const float* gate_b, const float* proj_w, const float* proj_b, void* y, int64_t npix,
+                      int HW, int T, int Cin, int Cout, int dilation, int G, float eps, int dtype, hipStream_t stream) {
+  if (npix <= 0 || T <= 0) return frl_fail(-2, "tcn_block_fwd: empty input");
+  if (proj_w == nullptr && Cin != Cout) return frl_fail(-2, "tcn_block_fwd: identity residual needs Cin == Cout");
+  int rc = frl_tcn_check(Cin, Cout, G, dtype);
+  if (rc) return rc;
+  TcnArgs a{npix, HW, T, dilation, Cin, Cout, G, eps};
+  const int pi = pad_class(Cin, dtype), po = pad_class(Cout, dtype);
+#define CALL(TT, NFI, MBO) return launch_tcn_fwd<TT, NFI, MBO>(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, y, a, stream);
+  if (dtype == FRL_F32) TCN_SWITCH_F32(pi, po, CALL)
+  else if (dtype == FRL_BF16) TCN_SWITCH_BF16(pi, po, CALL)
+#undef CALL
+  return frl_fail(-2, "tcn_block_fwd: unsupported dtype / widths");
+}
+
+// dx [.. Cin] = conv^T(dconv [.. Cout]) + (proj_w ? proj_w^T dres : dres)
+int frl_tcn_block_bwd_data(const void* dconv, const void* dres, const float* conv_w, const float* proj_w, void* dx, int64_t npix, int HW,
+                           int T, int Cin, int Cout, int dilation, int dtype, hipStream_t stream) {
+  TcnArgs a{npix, HW, T, dilation, Cout, Cin, 1, 0.f};   // roles swapped: input width Cout, output width Cin
+  const int pi = pad_class(Cout, dtype), po = pad_class(Cin, dtype);
+  if (pi < 0 || po < 0) return frl_fail(-2, "tcn: channel counts above 128 unsupported");
+  // Weff_k[o=ci][i=co] = conv_w[co][ci][2-k] -> so = 3, si = Cin*3, rev
+  const void* r = proj_w ? nullptr : dres;
+  const void* r2 = proj_w ? dres : nullptr;
+#define CALL(TT, NFI, MBO) return launch_tconv3<TT, NFI, MBO, NFI>(dconv, conv_w, 3, (int64_t)Cin * 3, 1, r, r2, proj_w, 1, Cin, Cout, dx, a, stream);
+  if (dtype == FRL_F32) TCN_SWITCH_F32(pi, po, CALL)
+  else if (dtype == FRL_BF16) TCN_SWITCH_BF16(pi, po, CALL)
+#undef CALL
+  return frl_fail(-2, "tcn_block_bwd_data: unsupported dtype / widths");
+}
+
+}  // extern "C"

@@ -37,6 +37,30 @@ SIGNATURES = {
     "frl_vq_assign_fwd": (c_int, [P, P, L, I, I, P, P, P, P, I, P, S, P]),
     "frl_vq_bwd": (c_int, [P, P, P, P, P, P, F, L, I, I, P, P, P, I, P, S, P]),
     "frl_vq_ema_update": (c_int, [P, P, I, I, F, F, P, P, P, P]),
+    "frl_groupnorm_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, F, I, I, P]),
+    "frl_groupnorm_bwd_workspace_bytes": (S, [I, I, I]),
+    "frl_groupnorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P, S, P]),
+    "frl_mse_workspace_bytes": (S, []),
+    "frl_mse_fwd": (c_int, [P, P, P, L, I, P, I, P, S, P]),
+    "frl_mse_bwd": (c_int, [P, P, P, P, P, L, I, P, I, P]),
+    "frl_film_modulate_fwd": (c_int, [P, P, P, P, L, I, L, I, I, P]),
+    "frl_film_modulate_bwd": (c_int, [P, P, P, P, P, P, L, I, L, I, I, P]),
+    "frl_gate_blend_fwd": (c_int, [P, P, P, F, P, P, L, I, P]),
+    "frl_gate_blend_bwd": (c_int, [P, P, P, P, F, P, P, L, I, P]),
+    "frl_mean_time_fwd": (c_int, [P, P, L, I, L, I, P]),
+    "frl_add": (c_int, [P, P, P, L, I, P]),
+    "frl_conv3x3_fwd": (c_int, [P, P, P, P, I, I, I, I, I, I, I, P]),
+    "frl_conv3x3_bwd_data": (c_int, [P, P, I, P, P, I, I, I, I, I, I, P]),
+    "frl_conv3x3_bwd_weight_workspace_bytes": (S, [I, I, I, I, I]),
+    "frl_conv3x3_bwd_weight": (c_int, [P, P, I, P, P, P, I, I, I, I, I, I, P, S, I, P]),
+    "frl_sobel_fwd": (c_int, [P, P, I, I, I, I, I, P]),
+    "frl_sobel_bwd": (c_int, [P, P, I, I, I, I, I, P]),
+    "frl_edge_smooth_stencil_fwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "frl_edge_smooth_stencil_bwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "frl_tcn_block_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, F, I, P]),
+    "frl_tcn_block_bwd_data": (c_int, [P, P, P, P, P, L, I, I, I, I, I, I, P]),
+    "frl_tcn_block_bwd_workspace_bytes": (S, [L, I]),
+    "frl_tcn_block_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, F, I, P, S, P]),
 }
 
 

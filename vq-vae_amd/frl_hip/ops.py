@@ -138,3 +138,232 @@ def vq_ema_update(sums, counts, ema_count, ema_sum, codebook, decay: float, eps:
     k, d = codebook.shape
     check(_lib.load().frl_vq_ema_update(_p(sums), _p(counts), k, d, float(decay), float(eps), _p(ema_count),
                                         _p(ema_sum), _p(codebook), _stream()), "frl_vq_ema_update")
+
+
+# ----------------------------------------------------------------------------------------------
+# GroupNorm over NHWC rows (csrc/norm.hip)
+# ----------------------------------------------------------------------------------------------
+def groupnorm_fwd(x: torch.Tensor, gamma, beta, groups: int, eps: float = 1e-5, relu: bool = False):
+    """x [B, ..., C] -> (y, mean [B,G], rstd [B,G])."""
+    b, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (b * c)
+    _chk_rows(x, c, "groupnorm.x")
+    y = torch.empty_like(x)
+    mean = torch.empty(b, groups, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    check(_lib.load().frl_groupnorm_fwd(_p(x), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta")), _p(y), _p(mean), _p(rstd),
+                                        b, hw, c, groups, float(eps), int(relu), _dt(x), _stream()), "frl_groupnorm_fwd")
+    return y, mean, rstd
+
+
+def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, groups: int, relu: bool = False):
+    b, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (b * c)
+    lib = _lib.load()
+    ws = workspace(lib.frl_groupnorm_bwd_workspace_bytes(b, c, groups), x.device)
+    dx = torch.empty_like(x)
+    dg = torch.empty(c, dtype=torch.float32, device=x.device)
+    db = torch.empty(c, dtype=torch.float32, device=x.device)
+    check(lib.frl_groupnorm_bwd(_p(dy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), b, hw, c,
+                                groups, int(relu), _dt(x), _p(ws), ws.numel(), _stream()), "frl_groupnorm_bwd")
+    return dx, dg, db
+
+
+# ----------------------------------------------------------------------------------------------
+# streaming elementwise ops (csrc/elementwise.hip)
+# ----------------------------------------------------------------------------------------------
+def mse_fwd(pred: torch.Tensor, target: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Returns stats f32 [2] = {mean squared error over valid elements, number of valid elements}."""
+    c = pred.shape[-1]
+    _chk_rows(pred, c, "mse.pred")
+    _chk_rows(target, c, "mse.target")
+    lib = _lib.load()
+    ws = workspace(lib.frl_mse_workspace_bytes(), pred.device)
+    out = torch.empty(2, dtype=torch.float32, device=pred.device)
+    check(lib.frl_mse_fwd(_p(pred), _p(target), _p(mask), pred.numel() // c, c, _p(out), _dt(pred), _p(ws), ws.numel(),
+                          _stream()), "frl_mse_fwd")
+    return out
+
+
+def mse_bwd(pred, target, mask, gscale: Optional[torch.Tensor], stats) -> torch.Tensor:
+    c = pred.shape[-1]
+    d = torch.empty_like(pred)
+    check(_lib.load().frl_mse_bwd(_p(pred), _p(target), _p(mask), _p(gscale), _p(stats), pred.numel() // c, c, _p(d),
+                                  _dt(pred), _stream()), "frl_mse_bwd")
+    return d
+
+
+def film_modulate_fwd(h: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+    """h [B,T,HW..,C], gamma/beta [B,HW..,C]."""
+    b, t, c = h.shape[0], h.shape[1], h.shape[-1]
+    hw = h.numel() // (b * t * c)
+    out = torch.empty_like(h)
+    check(_lib.load().frl_film_modulate_fwd(_p(h), _p(gamma), _p(beta), _p(out), b, t, hw, c, _dt(h), _stream()),
+          "frl_film_modulate_fwd")
+    return out
+
+
+def film_modulate_bwd(dout, h, gamma):
+    b, t, c = h.shape[0], h.shape[1], h.shape[-1]
+    hw = h.numel() // (b * t * c)
+    dh = torch.empty_like(h)
+    dg = torch.empty_like(gamma)
+    db = torch.empty_like(gamma)
+    check(_lib.load().frl_film_modulate_bwd(_p(dout), _p(h), _p(gamma), _p(dh), _p(dg), _p(db), b, t, hw, c, _dt(h),
+                                            _stream()), "frl_film_modulate_bwd")
+    return dh, dg, db
+
+
+def gate_blend_fwd(smoothed, residual, gate_raw, min_gate: float):
+    out = torch.empty_like(smoothed)
+    gate = torch.empty_like(smoothed)
+    check(_lib.load().frl_gate_blend_fwd(_p(smoothed), _p(residual), _p(gate_raw), float(min_gate), _p(out), _p(gate),
+                                         smoothed.numel(), _dt(smoothed), _stream()), "frl_gate_blend_fwd")
+    return out, gate
+
+
+def gate_blend_bwd(dout, dgate_ext, residual, gate_raw, min_gate: float):
+    dres = torch.empty_like(dout)
+    dgraw = torch.empty_like(dout)
+    check(_lib.load().frl_gate_blend_bwd(_p(dout), _p(dgate_ext), _p(residual), _p(gate_raw), float(min_gate), _p(dres),
+                                         _p(dgraw), dout.numel(), _dt(dout), _stream()), "frl_gate_blend_bwd")
+    return dres, dgraw
+
+
+def mean_time(tile: torch.Tensor) -> torch.Tensor:
+    """tile [B,T,H,W,C] -> [B,H,W,C]."""
+    b, t = tile.shape[0], tile.shape[1]
+    out = torch.empty((b,) + tuple(tile.shape[2:]), dtype=tile.dtype, device=tile.device)
+    check(_lib.load().frl_mean_time_fwd(_p(tile), _p(out), b, t, out.numel() // b, _dt(tile), _stream()), "frl_mean_time_fwd")
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(a)
+    check(_lib.load().frl_add(_p(a), _p(b), _p(out), a.numel(), _dt(a), _stream()), "frl_add")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# 3x3 convolution (csrc/conv3x3.hip); x [B,H,W,Cin], w [Cout,Cin,3,3]
+# ----------------------------------------------------------------------------------------------
+def conv3x3_fwd(x, w, bias, act: int = ACT_NONE):
+    b, h, wd, cin = x.shape
+    cout = w.shape[0]
+    _chk_rows(x, cin, "conv3x3.x")
+    y = torch.empty(b, h, wd, cout, dtype=x.dtype, device=x.device)
+    check(_lib.load().frl_conv3x3_fwd(_p(x), _p(_f32(w, "w")), _p(_f32(bias, "bias")), _p(y), b, h, wd, cin, cout, act,
+                                      _dt(x), _stream()), "frl_conv3x3_fwd")
+    return y
+
+
+def conv3x3_bwd_data(dy, w, y=None, act: int = ACT_NONE):
+    b, h, wd, cout = dy.shape
+    cin = w.shape[1]
+    dx = torch.empty(b, h, wd, cin, dtype=dy.dtype, device=dy.device)
+    check(_lib.load().frl_conv3x3_bwd_data(_p(dy), _p(y), act, _p(_f32(w, "w")), _p(dx), b, h, wd, cin, cout, _dt(dy),
+                                           _stream()), "frl_conv3x3_bwd_data")
+    return dx
+
+
+def conv3x3_bwd_weight(dy, x, y=None, act: int = ACT_NONE, scalar_frags: bool = False):
+    b, h, wd, cout = dy.shape
+    cin = x.shape[-1]
+    lib = _lib.load()
+    ws = workspace(lib.frl_conv3x3_bwd_weight_workspace_bytes(b, h, wd, cin, cout), dy.device)
+    dw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=dy.device)
+    db = torch.empty(cout, dtype=torch.float32, device=dy.device)
+    check(lib.frl_conv3x3_bwd_weight(_p(dy), _p(y), act, _p(x), _p(dw), _p(db), b, h, wd, cin, cout, _dt(dy), _p(ws),
+                                     ws.numel(), 1 if scalar_frags else 0, _stream()), "frl_conv3x3_bwd_weight")
+    return dw, db
+
+
+# ----------------------------------------------------------------------------------------------
+# fixed stencils of EdgeAwareSmoothingConv2D (csrc/stencil.hip)
+# ----------------------------------------------------------------------------------------------
+def sobel_fwd(x):
+    b, h, w, c = x.shape
+    g = torch.empty(b, h, w, 2 * c, dtype=x.dtype, device=x.device)
+    check(_lib.load().frl_sobel_fwd(_p(x), _p(g), b, h, w, c, _dt(x), _stream()), "frl_sobel_fwd")
+    return g
+
+
+def sobel_bwd(dg):
+    b, h, w, c2 = dg.shape
+    dx = torch.empty(b, h, w, c2 // 2, dtype=dg.dtype, device=dg.device)
+    check(_lib.load().frl_sobel_bwd(_p(dg), _p(dx), b, h, w, c2 // 2, _dt(dg), _stream()), "frl_sobel_bwd")
+    return dx
+
+
+def edge_smooth_fwd(x, a_logit, b_logit, rank: int, coarse_dilation: int):
+    b, h, w, c = x.shape
+    sm, res = torch.empty_like(x), torch.empty_like(x)
+    a_soft, b_soft = torch.empty_like(a_logit), torch.empty_like(b_logit)
+    check(_lib.load().frl_edge_smooth_stencil_fwd(_p(x), _p(a_logit), _p(b_logit), _p(sm), _p(res), _p(a_soft), _p(b_soft),
+                                                  b, h, w, c, rank, coarse_dilation, _dt(x), _stream()),
+          "frl_edge_smooth_stencil_fwd")
+    return sm, res, a_soft, b_soft
+
+
+def edge_smooth_bwd(d_smoothed, x, a_soft, b_soft, rank: int, coarse_dilation: int):
+    b, h, w, c = x.shape
+    dx = torch.empty_like(x)
+    da, db = torch.empty_like(a_soft), torch.empty_like(b_soft)
+    check(_lib.load().frl_edge_smooth_stencil_bwd(_p(d_smoothed), _p(x), _p(a_soft), _p(b_soft), _p(dx), _p(da), _p(db),
+                                                  b, h, w, c, rank, coarse_dilation, _dt(x), _stream()),
+          "frl_edge_smooth_stencil_bwd")
+    return dx, da, db
+
+
+# ----------------------------------------------------------------------------------------------
+# fused TCN block (csrc/tcn_fwd.hip, tcn_bwd.hip); x [B,T,HW..,Cin]
+# ----------------------------------------------------------------------------------------------
+def tcn_block_fwd(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, dilation: int, groups: int,
+                  eps: float = 1e-5):
+    b, t, cin = x.shape[0], x.shape[1], x.shape[-1]
+    cout = conv_w.shape[0]
+    hw = x.numel() // (b * t * cin)
+    y = torch.empty(x.shape[:-1] + (cout,), dtype=x.dtype, device=x.device)
+    check(_lib.load().frl_tcn_block_fwd(_p(x), _p(_f32(conv_w, "conv_w")), _p(conv_b), _p(gn_w), _p(gn_b),
+                                        _p(_f32(gate_w.reshape(cout, cout), "gate_w")), _p(gate_b), _p(proj_w), _p(proj_b),
+                                        _p(y), b * hw, hw, t, cin, cout, dilation, groups, float(eps), _dt(x), _stream()),
+          "frl_tcn_block_fwd")
+    return y
+
+
+def tcn_block_bwd(x, dy, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, dilation: int, groups: int,
+                  eps: float = 1e-5):
+    """Returns dict(dx, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b[, proj_w, proj_b]) gradients."""
+    b, t, cin = x.shape[0], x.shape[1], x.shape[-1]
+    cout = conv_w.shape[0]
+    hw = x.numel() // (b * t * cin)
+    npix = b * hw
+    lib = _lib.load()
+    dev = x.device
+    oshape = x.shape[:-1] + (cout,)
+    dconv = torch.empty(oshape, dtype=x.dtype, device=dev)
+    dgpre, normed, dres = torch.empty_like(dconv), torch.empty_like(dconv), torch.empty_like(dconv)
+    dgam = torch.empty(cout, dtype=torch.float32, device=dev)
+    dbet = torch.empty(cout, dtype=torch.float32, device=dev)
+    gate_w2 = gate_w.reshape(cout, cout)
+    ws = workspace(lib.frl_tcn_block_bwd_workspace_bytes(npix, cout), dev)
+    check(lib.frl_tcn_block_bwd(_p(x), _p(dy), _p(conv_w), _p(conv_b), _p(gn_w), _p(gn_b), _p(gate_w2), _p(gate_b), _p(proj_w),
+                                _p(proj_b), _p(dconv), _p(dgpre), _p(normed), _p(dres), _p(dgam), _p(dbet), npix, hw, t, cin,
+                                cout, dilation, groups, float(eps), _dt(x), _p(ws), ws.numel(), _stream()), "frl_tcn_block_bwd")
+    dx = torch.empty_like(x)
+    check(lib.frl_tcn_block_bwd_data(_p(dconv), _p(dres), _p(conv_w), _p(proj_w), _p(dx), npix, hw, t, cin, cout, dilation,
+                                     _dt(x), _stream()), "frl_tcn_block_bwd_data")
+    p = b * t * hw
+    dw = torch.empty(cout, cin, 3, dtype=torch.float32, device=dev)
+    dcb = torch.empty(cout, dtype=torch.float32, device=dev)
+    ws2 = workspace(lib.frl_conv1x1_bwd_weight_workspace_bytes(p, max(cin, cout), cout), dev)
+    for k in range(3):
+        check(lib.frl_conv_tap_bwd_weight(_p(dconv), None, 0, _p(x), ctypes.c_void_p(dw.data_ptr() + 4 * k), cin * 3, 3,
+                                          _p(dcb) if k == 1 else None, p, cin, cout, hw, t, (k - 1) * dilation, _dt(x),
+                                          _p(ws2), ws2.numel(), 0, _stream()), "frl_conv_tap_bwd_weight")
+    dgw, dgb = conv1x1_bwd_weight(dgpre, normed)
+    out = dict(dx=dx, conv_w=dw, conv_b=dcb, gn_w=dgam, gn_b=dbet, gate_w=dgw.reshape(gate_w.shape), gate_b=dgb)
+    if proj_w is not None:
+        dpw, dpb = conv1x1_bwd_weight(dres, x)
+        out.update(proj_w=dpw.reshape(proj_w.shape), proj_b=dpb)
+    return out
