@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- tiles/sec of the full VQ-VAE train step (encoder -> VQ -> decoders, fwd + bwd + AdamW) on MI355X.
+
+Contract: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run, one rank per GPU).
+Prints ONE JSON line on rank 0: metric tiles/sec on BASELINE.json configs[1] (B=256 tiles of 5x32x32x64 per GPU, K=512,
+d=64, bf16 activations, float32 master weights), plus
+  * "roofline": the dominant kernel's achieved rate, timed live with HIP events on the launch stream;
+  * "kernels":  per-kernel-family time shares from the same events (conv MFMA %, VQ HBM GB/s of the north star);
+  * "cpu_baseline": the CPU oracle (reference encoder math + oracle VQ/decoder) timed on this node's host cores, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "vq-vae_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="tiles per GPU (weak scaling)")
+    ap.add_argument("--codebook", type=int, default=512)
+    ap.add_argument("--emb-dim", type=int, default=64)
+    ap.add_argument("--time", type=int, default=5)
+    ap.add_argument("--size", type=int, default=32)
+    ap.add_argument("--features", type=int, default=64)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-finite-check", action="store_true")
+    return ap.parse_args()
+
+
+def conv_flops_per_tile(T, S, F, d, zp, hidden=128):
+    """Algorithmic dense-contraction FLOPs per tile, forward, train step = 3x."""
+    px = S * S
+    enc = 2 * (F * 128 + 128 * d)
+    spatial = 2 * (2 * d * 64 * 9) + 2 * (64 * 32) + 2 * (64 * d * 4) + 2 * (d * 64 * 9) + 2 * (64 * d * 9)
+    tcn = T * 3 * (2 * (F * 64 * 3) + 2 * 64 * 64)              # per pixel, three blocks of 64 channels
+    head = T * 2 * 64 * zp + 2 * (2 * (d * 32) + 2 * (32 * zp))
+    dec = 2 * (d * hidden + hidden * F) + T * 2 * (zp * hidden + hidden * F)
+    return px * (enc + spatial + tcn + head + dec)
+
+
+def cpu_baseline(args):
+    """Oracle train step on the host cores (rank 0, N=1): bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import frl_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    bs = 8
+    g = torch.Generator().manual_seed(0)
+    from frl_hip.models import VQVAE
+    m = VQVAE(in_features=args.features, codebook_size=args.codebook, emb_dim=args.emb_dim, type_encoder_dropout=0.0,
+              phase_tcn_dropout=0.0)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    sd["quant.codebook"] = torch.randn(args.codebook, args.emb_dim, generator=g)
+    tr = O.OracleTrainer(sd, dict(beta=0.25), lr=1e-4, total_steps=100)
+    tiles = [torch.randn(bs, args.time, args.size, args.size, args.features, generator=g) for _ in range(2)]
+    tr.step(tiles[0])
+    t0 = time.perf_counter()
+    n = 3
+    for i in range(n):
+        tr.step(tiles[i % 2])
+    dt = time.perf_counter() - t0
+    return {"value": round(bs * n / dt, 2), "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"{n} timed oracle train steps of {bs} tiles (K={args.codebook}, d={args.emb_dim}, f32 torch CPU, "
+                      f"float64 argmin), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path is HIP-only (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)     # "nccl" == RCCL on ROCm
+    from frl_hip import ops
+    from frl_hip.data import SyntheticTileStream
+    from frl_hip.models import VQVAE
+    from frl_hip.training.trainer import VQVAETrainer
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    model = VQVAE(in_features=args.features, codebook_size=args.codebook, emb_dim=args.emb_dim, beta=0.25,
+                  type_encoder_dropout=0.0, phase_tcn_dropout=0.0, compute_dtype=dtype).to(dev)
+    with torch.no_grad():   # well-separated codebook so that all codes are used
+        model.quant.codebook.copy_(torch.randn(args.codebook, args.emb_dim, generator=torch.Generator().manual_seed(7)))
+    trainer = VQVAETrainer(model, lr=1e-4, total_steps=10000, check_finite=not args.no_finite_check)
+    stream = SyntheticTileStream(args.batch, args.time, args.size, args.features, device=dev, dtype=dtype, seed=1234 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(stream.next())
+    timing = (not args.no_kernel_timing) and rank == 0
+    barrier()
+    if timing:
+        ops.set_timing(True)
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = trainer.step(stream.next())
+    barrier()
+    dt = time.perf_counter() - t0
+    ksum = ops.timing_summary() if timing else {}
+    ops.set_timing(False)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    tiles = args.batch * world * args.steps
+    out = {
+        "metric": "tiles/sec", "value": round(tiles / dt, 1), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: full VQ-VAE train step (type path + VQ + decoders + dense phase path, "
+                               f"fwd+bwd+clip+AdamW), {args.batch} tiles/GPU of {args.time}x{args.size}x{args.size}x{args.features}, "
+                               f"K={args.codebook}, d={args.emb_dim}, dropout 0.0",
+                   "global_batch": args.batch * world, "parallelism": f"dp{world}", "finite_check": not args.no_finite_check,
+                   "loss": round(float(last["loss"]), 5), "perplexity": round(float(last["perplexity"]), 2)},
+    }
+    if ksum:
+        n = args.batch * args.size * args.size                      # vectors / pixels per step
+        s = 2 if args.dtype == "bf16" else 4
+        fam = {k: {"calls_per_step": c / args.steps, "ms_per_step": round(ms / args.steps, 4)} for k, (c, ms) in ksum.items()}
+        out["kernels"] = fam
+        # --- VQ assign: HBM roofline, algorithmic bytes = 2*d*s + 4 per vector (+ K*d*4 codebook once)
+        vq_ms = ksum["vq_assign"][1] / ksum["vq_assign"][0]
+        vq_bytes = n * (2 * args.emb_dim * s + 4) + args.codebook * args.emb_dim * 4
+        out["vq_hbm"] = {"GB/s": round(vq_bytes / vq_ms / 1e6, 1), "frac": round(vq_bytes / vq_ms / 1e6 / HBM_PEAK_GBS, 4),
+                         "ms": round(vq_ms, 4), "note": "span = prep + assign + float64 fix-up + finalize launches"}
+        # --- conv MFMA: all dense contractions of the step vs time spent in conv/tcn kernels
+        conv_keys = [k for k in ksum if k.startswith(("conv", "tcn"))]
+        conv_ms = sum(ksum[k][1] for k in conv_keys if k != "conv1x1_bwd_weight" or True) / args.steps
+        # tcn_block_bwd's span already contains its nested wgrad calls; subtract the nested pointwise wgrad time once
+        flops = 3 * conv_flops_per_tile(args.time, args.size, args.features, args.emb_dim, model.z_phase_dim) * args.batch
+        out["conv_mfma"] = {"TFLOP/s": round(flops / conv_ms / 1e9, 1), "frac": round(flops / conv_ms / 1e9 / MFMA_BF16_PEAK_TF, 4),
+                            "ms_per_step": round(conv_ms, 3), "note": "algorithmic 3x fwd dense FLOPs / event time of conv+tcn ops"}
+        # --- dominant op -> headline roofline object
+        dom = max((k for k in ksum if k != "conv1x1_bwd_weight"), key=lambda k: ksum[k][1])
+        out["roofline"] = roofline_for(dom, ksum, args, model, n, s)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def roofline_for(name, ksum, args, model, n, s):
+    """Roofline entry for the op with the largest share of the step; per-launch algorithmic work / average launch time."""
+    calls, ms = ksum[name]
+    avg = ms / calls
+    T, F, d, zp = args.time, args.features, args.emb_dim, model.z_phase_dim
+    if name.startswith("tcn_block"):
+        rows = n * T
+        if name == "tcn_block_fwd":
+            flops = rows * (2 * 64 * 64 * 3 * 2 + 2 * 64 * 64)   # conv evaluated twice (stats + apply) + gate GEMM
+            algo = rows * (2 * 64 * 3 + 2 * 64 * 64 // 64) and rows * (2 * (64 * 64 * 3 + 64 * 64))
+        else:
+            algo = rows * (2 * (64 * 64 * 3 + 64 * 64)) * 2       # backward of conv + gate: data + weight gradients
+        return {"kernel": name, "bound": "mfma", "achieved": round(algo / avg / 1e9, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(algo / avg / 1e9 / MFMA_BF16_PEAK_TF, 4), "traffic": None, "avg_ms": round(avg, 4)}
+    if name == "vq_assign":
+        b = n * (2 * d * s + 4) + args.codebook * d * 4
+        return {"kernel": name, "bound": "hbm", "achieved": round(b / avg / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(b / avg / 1e6 / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(avg, 4)}
+    return {"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+            "avg_ms": round(avg, 4)}
+
+
+if __name__ == "__main__":
+    main()

@@ -113,7 +113,7 @@ int frl_film_modulate_fwd(const void* h, const void* gamma, const void* beta, vo
 int frl_film_modulate_bwd(const void* dout, const void* h, const void* gamma, void* dh, void* dgamma, void* dbeta,
                           int64_t B, int T, int64_t HW, int C, int dtype, frl_stream_t stream);
 int frl_mean_time_fwd(const void* tile, void* out, int64_t B, int T, int64_t HWC, int dtype, frl_stream_t stream);
-int frl_add(const void* a, const void* b, void* out, int64_t n, int dtype, frl_stream_t stream);
+int frl_add(const void* a, const void* b, float scale_b, void* out, int64_t n, int dtype, frl_stream_t stream); /* out = a + scale_b*b */
 
 /* ---- masked L2 reconstruction loss -----------------------------------------------------------------------------
  * frl/losses/reconstruction.py:95-139 (loss_type "l2", reduction "mean"); out = {mean, n_valid_elements}. */

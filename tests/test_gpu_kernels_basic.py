@@ -134,7 +134,7 @@ def test_vq_bwd_and_ema(dtype):
     g = torch.Generator().manual_seed(9)
     gout = torch.randn(N, d, generator=g).to(dtype)
     idx, zq, stats, counts = ops.vq_assign(zt.to(dev), et.to(dev))
-    gs = torch.tensor([0.7], device=dev)
+    gs = torch.tensor([0.7, 0.7], device=dev)
     gz, ge, sums = ops.vq_bwd(gout.to(dev), zt.to(dev), et.to(dev), idx, counts, gs, 0.25, want_sums=True)
     zq_ref = e_eff[idx_ref].double()
     gz_ref = gout.double() + 0.7 * 0.25 * 2 / (N * d) * (zt.double() - zq_ref)

@@ -1,0 +1,193 @@
+"""Model-level parity on the GPU: frl_hip RepresentationModel / VQVAE vs the golden vectors generated from the reference
+(encoder: pinned) and vs the oracle's VQ-VAE step (quantizer / decoder: parity unpinned by the reference)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import frl_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+TINY_KW = dict(type_in_channels=8, phase_in_channels=8, z_type_dim=8, z_phase_dim=4, type_encoder_channels=(16, 8),
+               type_encoder_dropout=0.0, type_encoder_num_groups=4, spatial_conv_gate_hidden=8, phase_tcn_channels=(8, 8, 8),
+               phase_tcn_dropout=0.0, phase_tcn_num_groups=4)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _state(fx):
+    return {k[6:]: torch.from_numpy(fx[k]).float() for k in fx.files if k.startswith("state.")}
+
+
+def maxabs(a, b):
+    return float(np.abs(a.detach().float().cpu().numpy().astype(np.float64) - np.asarray(b, dtype=np.float64)).max())
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_tiny_forward_backward_matches_reference_golden(golden_dir, seed):
+    from frl_hip.models import RepresentationModel
+    fx = _load(golden_dir, f"tiny_seed{seed}")
+    m = RepresentationModel(**TINY_KW).to(DEV)
+    missing = m.load_state_dict(_state(fx), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    m.eval()
+    tile = torch.from_numpy(fx["tile"]).float().to(DEV)
+    x_type = tile.mean(1).permute(0, 3, 1, 2).contiguous().requires_grad_(True)      # [B,C,H,W]
+    x_phase = tile.permute(0, 4, 1, 2, 3).contiguous().requires_grad_(True)           # [B,C,T,H,W]
+    z, gate = m(x_type, return_gate=True)
+    assert z.shape == (2, 8, 8, 8) and maxabs(z, fx["z_type"]) < 1e-5 and maxabs(gate, fx["gate"]) < 1e-5
+    h = m.encoder(x_type.detach().permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)
+    assert maxabs(h, fx["h"]) < 1e-5
+    zp = m.forward_phase(x_phase, z.detach())
+    assert zp.shape == (2, 4, 5, 8, 8) and maxabs(zp, fx["z_phase"]) < 1e-5
+    loss = z.float().pow(2).mean() + zp.float().pow(2).mean()
+    assert abs(loss.item() - float(fx["loss"])) < 1e-5
+    loss.backward()
+    assert maxabs(x_type.grad, fx["grad.x_type"]) < 1e-6 + 1e-4 * np.abs(fx["grad.x_type"]).max()
+    assert maxabs(x_phase.grad, fx["grad.x_phase"]) < 1e-6 + 1e-4 * np.abs(fx["grad.x_phase"]).max()
+    for name, p in m.named_parameters():
+        ref = fx["grad." + name]
+        assert maxabs(p.grad, ref) <= 1e-6 + 2e-4 * np.abs(ref).max(), name
+    # sparse path == dense path at the same pixels (representation.py:385-388)
+    yx = fx["loc_yx"]
+    xpx = x_phase.detach()[0][:, :, yx[:, 0], yx[:, 1]].permute(2, 0, 1).contiguous()
+    zpx = z.detach()[0][:, yx[:, 0], yx[:, 1]].permute(1, 0).contiguous()
+    zl, gam, bet, hpre = m.forward_phase_at_locations(xpx, zpx, return_film=True, return_pre_film=True)
+    assert zl.shape == (7, 5, 4) and maxabs(zl, fx["loc_z"]) < 1e-5
+    assert maxabs(gam, fx["loc_gamma"]) < 1e-5 and maxabs(bet, fx["loc_beta"]) < 1e-5 and maxabs(hpre, fx["loc_hpre"]) < 1e-5
+
+
+def test_full_size_tile_within_1e5_of_reference(golden_dir):
+    """BASELINE north_star tolerance: latents within 1e-5 (float32 parity mode) of the reference CPU path."""
+    from frl_hip.models import RepresentationModel
+    fx = _load(golden_dir, "full_seed0")
+    m = RepresentationModel(64, 64, type_encoder_dropout=0.0, phase_tcn_dropout=0.0).to(DEV).eval()
+    sd = _state(fx)
+    # the reference default has Dropout2d modules (indices 0,1,2,3 | 4,5); dropout-free build has (0,1,2 | 3,4)
+    remap = {"encoder.layers.4.weight": "encoder.layers.3.weight", "encoder.layers.5.weight": "encoder.layers.4.weight",
+             "encoder.layers.5.bias": "encoder.layers.4.bias"}
+    sd = {remap.get(k, k): v for k, v in sd.items()}
+    m.load_state_dict(sd, strict=True)
+    tile = torch.from_numpy(fx["tile"]).float().to(DEV)
+    x_type = tile.mean(1)
+    z, gate = m.forward_nhwc(x_type, return_gate=True)
+    assert maxabs(z.permute(0, 3, 1, 2), fx["z_type"]) < 1e-5
+    assert maxabs(gate.permute(0, 3, 1, 2), fx["gate"]) < 1e-5
+    zp = m.forward_phase_nhwc(tile, z)
+    assert maxabs(zp.permute(0, 4, 1, 2, 3), fx["z_phase"]) < 1e-5
+
+
+def test_reference_default_state_dict_keys_load_with_dropout_modules(golden_dir):
+    from frl_hip.models import RepresentationModel
+    fx = _load(golden_dir, "full_seed0")
+    m = RepresentationModel(64, 64)       # class defaults: dropout 0.1 -> Sequential indices 0,1,2,3,4,5
+    res = m.load_state_dict(_state(fx), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert sum(p.numel() for p in m.parameters()) == 238788
+
+
+def test_min_gate_and_projection(golden_dir):
+    from frl_hip.models import RepresentationModel
+    fx = _load(golden_dir, "tiny_mingate_proj")
+    kw = dict(TINY_KW, phase_in_channels=16)
+    m = RepresentationModel(**kw).to(DEV).eval()
+    m.load_state_dict(_state(fx), strict=True)
+    m.set_spatial_min_gate(float(fx["min_gate"]))
+    tile = torch.from_numpy(fx["tile"]).float().to(DEV)
+    z, gate = m.forward_nhwc(tile.mean(1), return_gate=True)
+    assert maxabs(z.permute(0, 3, 1, 2), fx["z_type"]) < 1e-5 and maxabs(gate.permute(0, 3, 1, 2), fx["gate"]) < 1e-5
+    assert gate.min().item() >= float(fx["min_gate"]) - 1e-6
+    xp = torch.from_numpy(fx["xp16"]).float().to(DEV)                    # [N,16,T]
+    out = m.phase_tcn(xp.permute(2, 0, 1).unsqueeze(0).contiguous())[0].permute(1, 2, 0)
+    assert maxabs(out, fx["tcn_out"]) < 1e-5
+    m.set_spatial_min_gate(1.0)                                           # gate floor 1 => output == encoder output
+    z1 = m.forward_nhwc(tile.mean(1))
+    h = m.encoder(tile.mean(1).contiguous())
+    assert maxabs(z1, h.detach().cpu().numpy()) < 1e-5
+
+
+def _vqvae_from_fixture(fx, dtype=torch.float32):
+    from frl_hip.models import VQVAE
+    m = VQVAE(in_features=8, codebook_size=16, emb_dim=8, beta=0.25, hidden=16, z_phase_dim=4, type_encoder_channels=(16, 8),
+              type_encoder_dropout=0.0, type_encoder_num_groups=4, spatial_conv_gate_hidden=8, phase_tcn_channels=(8, 8, 8),
+              phase_tcn_dropout=0.0, phase_tcn_num_groups=4, compute_dtype=dtype).to(DEV)
+    res = m.load_state_dict(_state(fx), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    return m
+
+
+def test_vqvae_step_matches_oracle_fixture(golden_dir):
+    fx = _load(golden_dir, "vqvae_tiny_seed0")
+    m = _vqvae_from_fixture(fx)
+    tiles = torch.from_numpy(fx["tiles"]).float().to(DEV)
+    m.train()
+    out = m.forward_tiles(tiles[0])
+    assert np.array_equal(out["idx"].cpu().numpy().astype(np.int64), fx["idx"])          # bit-exact indices
+    assert abs(out["loss"].item() - float(fx["loss"])) < 1e-5
+    assert abs(out["l_type"].item() - float(fx["l_type"])) < 1e-5 and abs(out["l_phase"].item() - float(fx["l_phase"])) < 1e-5
+    assert abs(out["vq_loss"].item() - float(fx["vq_loss"])) < 1e-5
+    assert abs(out["perplexity"].item() - float(fx["perplexity"])) < 1e-4
+    assert maxabs(out["xhat_type"].permute(0, 3, 1, 2), fx["xhat_type"]) < 1e-5
+    out["loss"].backward()
+    for name, p in m.named_parameters():
+        ref = fx["grad." + name]
+        assert maxabs(p.grad, ref) <= 1e-6 + 2e-4 * np.abs(ref).max(), name
+    # legacy model(batch) contract
+    cont_pred, cat_logits, canopy_pred, vq_loss, perp = m({"tile": tiles[0]})
+    assert cat_logits == {} and cont_pred.shape == (2, 8, 8, 8) and canopy_pred.shape == (2, 5, 8, 8, 8)
+    assert "quant.codebook" in dict(m.named_parameters()) and m.quant.codebook_size == 16 and m.quant.emb_dim == 8
+
+
+def test_three_step_loss_trajectory_matches_oracle(golden_dir):
+    from frl_hip.training.trainer import VQVAETrainer
+    fx = _load(golden_dir, "vqvae_tiny_seed0")
+    m = _vqvae_from_fixture(fx)
+    tr = VQVAETrainer(m, lr=1e-3, total_steps=10)
+    tiles = torch.from_numpy(fx["tiles"]).float().to(DEV)
+    traj = [tr.step(tiles[i])["loss"].item() for i in range(3)]
+    assert np.abs(np.asarray(traj) - fx["traj"]).max() < 2e-5, (traj, fx["traj"])
+
+
+def test_bf16_mode_tracks_oracle_and_indices_are_exact(golden_dir):
+    """Performance mode: bf16 storage cannot meet 1e-5; check agreement at bf16 resolution and that the VQ indices are the
+    exact float64 argmin of the bf16 latents the encoder actually produced."""
+    fx = _load(golden_dir, "vqvae_tiny_seed0")
+    m = _vqvae_from_fixture(fx, torch.bfloat16)
+    tiles = torch.from_numpy(fx["tiles"]).float().to(DEV)
+    out = m.forward_tiles(tiles[0])
+    assert abs(out["loss"].item() - float(fx["loss"])) < 0.05 * float(fx["loss"])
+    z = out["z_type"].detach().float().cpu().reshape(-1, 8)
+    e = m.quant.codebook.detach().cpu().to(torch.bfloat16).float()
+    idx_ref = O.vq_argmin_np(z.numpy(), e.numpy())
+    assert np.array_equal(out["idx"].cpu().numpy().astype(np.int64), idx_ref)
+    out["loss"].backward()
+    for name, p in m.named_parameters():
+        ref = fx["grad." + name]
+        assert np.isfinite(p.grad.cpu().numpy()).all()
+        if np.abs(ref).max() > 1e-4:
+            cos = float((p.grad.cpu().double().flatten() @ torch.from_numpy(ref).double().flatten()) /
+                        (p.grad.cpu().double().norm() * np.linalg.norm(ref) + 1e-30))
+            assert cos > 0.97, (name, cos)
+
+
+def test_ema_quantizer_updates_codebook():
+    from frl_hip.models import VQVAE
+    torch.manual_seed(0)
+    m = VQVAE(in_features=8, codebook_size=16, emb_dim=8, hidden=16, quantizer="ema", z_phase_dim=4, type_encoder_channels=(16, 8),
+              type_encoder_dropout=0.0, type_encoder_num_groups=4, spatial_conv_gate_hidden=8, phase_tcn_channels=(8, 8, 8),
+              phase_tcn_dropout=0.0, phase_tcn_num_groups=4).to(DEV).train()
+    assert not m.quant.codebook.requires_grad
+    before = m.quant.codebook.detach().clone()
+    tile = torch.randn(2, 5, 8, 8, 8, device=DEV)
+    out = m.forward_tiles(tile)
+    z = out["z_type"].detach().reshape(-1, 8).cpu().double()
+    idx = out["idx"].cpu().long()
+    cb, cnt, sm = O.vq_ema_update(before.cpu().double(), torch.zeros(16, dtype=torch.float64), before.cpu().double(), z, idx, 0.99, 1e-5)
+    assert (m.quant.codebook.detach().cpu().double() - cb).abs().max() <= 1e-5 * max(1.0, cb.abs().max().item())
+    out["loss"].backward()
+    assert m.quant.codebook.grad is None

@@ -342,7 +342,7 @@ static int launch_c3(const void* x, const void* xm, int mask_act, const float* w
   auto kern = conv3x3_kernel<T, NF>;
   FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int tiles = B * ((H + C3_TH - 1) / C3_TH) * ((W + C3_TW - 1) / C3_TW);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, (const T*)x, (const T*)xm, mask_act, w, so, si, tap_rev, bias, (T*)y, B,
+  FRL_LAUNCH(kern, dim3(tiles), dim3(256), lds, st, (const T*)x, (const T*)xm, mask_act, w, so, si, tap_rev, bias, (T*)y, B,
                      H, W, Cin, Cout, act);
   return frl_check_launch("conv3x3");
 }
@@ -399,15 +399,15 @@ int frl_conv3x3_bwd_weight(const void* dy, const void* y, int act, const void* x
       const size_t lds = ((size_t)128 * (64 + 4) + (size_t)180 * (32 + 4)) * 4;
       auto kern = conv3x3_wgrad_kernel<float, 2, 2>;
       FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, stream, (const float*)dy, (const float*)ym, act, (const float*)x, (float*)ws,
+      FRL_LAUNCH(kern, dim3(nwg), dim3(256), lds, stream, (const float*)dy, (const float*)ym, act, (const float*)x, (float*)ws,
                          B, H, W, Cin, Cout, oc_base, tpw, 0);
     } else if (dtype == FRL_BF16) {
       const size_t lds = ((size_t)128 * (64 + 8) + (size_t)180 * (64 + 8)) * 2;
       auto kern = conv3x3_wgrad_kernel<bf16, 4, 4>;
-      hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, stream, (const bf16*)dy, (const bf16*)ym, act, (const bf16*)x, (float*)ws, B,
+      FRL_LAUNCH(kern, dim3(nwg), dim3(256), lds, stream, (const bf16*)dy, (const bf16*)ym, act, (const bf16*)x, (float*)ws, B,
                          H, W, Cin, Cout, oc_base, tpw, (flags & 1) ? 0 : 1);
     } else return frl_fail(-2, "conv3x3_bwd_weight: bad dtype");
-    hipLaunchKernelGGL(conv3x3_slab_reduce_kernel, dim3((unsigned)((slab_n + 255) / 256)), dim3(256), 0, stream, (const float*)ws, nwg, 64,
+    FRL_LAUNCH(conv3x3_slab_reduce_kernel, dim3((unsigned)((slab_n + 255) / 256)), dim3(256), 0, stream, (const float*)ws, nwg, 64,
                        Cin * 9, oc_base, Cout, dw, dbias);
   }
   return frl_check_launch("conv3x3_bwd_weight");

@@ -173,14 +173,14 @@ __global__ __launch_bounds__(256) void mean_time_kernel(const T* __restrict__ ti
   }
 }
 
-// out = a + b (gradient accumulation for multi-use tensors)
+// out = a + scale_b * b (gradient accumulation / subtraction for multi-use tensors)
 template <typename T, int V>
-__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int64_t nvec) {
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, float sb, T* __restrict__ out, int64_t nvec) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
     float x[V], y[V];
     Vec<T>::load(a + i * V, x); Vec<T>::load(b + i * V, y);
 #pragma unroll
-    for (int e = 0; e < V; ++e) x[e] += y[e];
+    for (int e = 0; e < V; ++e) x[e] = fmaf(sb, y[e], x[e]);
     Vec<T>::store(out + i * V, x);
   }
 }
@@ -210,11 +210,11 @@ int frl_mse_fwd(const void* pred, const void* target, const uint8_t* mask, int64
 #define VOK(v) (C % (v) == 0)
   unsigned grid;
   EW_DISPATCH(dtype, VOK,
-    grid = ew_grid(P * (C / 4)); hipLaunchKernelGGL((mse_partial_kernel<float, 4>), dim3(grid), dim3(256), 0, stream, (const float*)pred, (const float*)target, mask, P, C, partial),
-    grid = ew_grid(P * C); hipLaunchKernelGGL((mse_partial_kernel<float, 1>), dim3(grid), dim3(256), 0, stream, (const float*)pred, (const float*)target, mask, P, C, partial),
-    grid = ew_grid(P * (C / 8)); hipLaunchKernelGGL((mse_partial_kernel<bf16, 8>), dim3(grid), dim3(256), 0, stream, (const bf16*)pred, (const bf16*)target, mask, P, C, partial),
-    grid = ew_grid(P * C); hipLaunchKernelGGL((mse_partial_kernel<bf16, 1>), dim3(grid), dim3(256), 0, stream, (const bf16*)pred, (const bf16*)target, mask, P, C, partial))
-  hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(64), 0, stream, (const double*)partial, (int)grid, out);
+    grid = ew_grid(P * (C / 4)); FRL_LAUNCH((mse_partial_kernel<float, 4>), dim3(grid), dim3(256), 0, stream, (const float*)pred, (const float*)target, mask, P, C, partial),
+    grid = ew_grid(P * C); FRL_LAUNCH((mse_partial_kernel<float, 1>), dim3(grid), dim3(256), 0, stream, (const float*)pred, (const float*)target, mask, P, C, partial),
+    grid = ew_grid(P * (C / 8)); FRL_LAUNCH((mse_partial_kernel<bf16, 8>), dim3(grid), dim3(256), 0, stream, (const bf16*)pred, (const bf16*)target, mask, P, C, partial),
+    grid = ew_grid(P * C); FRL_LAUNCH((mse_partial_kernel<bf16, 1>), dim3(grid), dim3(256), 0, stream, (const bf16*)pred, (const bf16*)target, mask, P, C, partial))
+  FRL_LAUNCH(mse_finalize_kernel, dim3(1), dim3(64), 0, stream, (const double*)partial, (int)grid, out);
   return frl_check_launch("mse_fwd");
 }
 
@@ -222,10 +222,10 @@ int frl_mse_fwd(const void* pred, const void* target, const uint8_t* mask, int64
 int frl_mse_bwd(const void* pred, const void* target, const uint8_t* mask, const float* gscale, const float* stats, int64_t P,
                 int C, void* dpred, int dtype, hipStream_t stream) {
   EW_DISPATCH(dtype, VOK,
-    hipLaunchKernelGGL((mse_bwd_kernel<float, 4>), dim3(ew_grid(P * (C / 4))), dim3(256), 0, stream, (const float*)pred, (const float*)target, mask, gscale, stats, P, C, (float*)dpred),
-    hipLaunchKernelGGL((mse_bwd_kernel<float, 1>), dim3(ew_grid(P * C)), dim3(256), 0, stream, (const float*)pred, (const float*)target, mask, gscale, stats, P, C, (float*)dpred),
-    hipLaunchKernelGGL((mse_bwd_kernel<bf16, 8>), dim3(ew_grid(P * (C / 8))), dim3(256), 0, stream, (const bf16*)pred, (const bf16*)target, mask, gscale, stats, P, C, (bf16*)dpred),
-    hipLaunchKernelGGL((mse_bwd_kernel<bf16, 1>), dim3(ew_grid(P * C)), dim3(256), 0, stream, (const bf16*)pred, (const bf16*)target, mask, gscale, stats, P, C, (bf16*)dpred))
+    FRL_LAUNCH((mse_bwd_kernel<float, 4>), dim3(ew_grid(P * (C / 4))), dim3(256), 0, stream, (const float*)pred, (const float*)target, mask, gscale, stats, P, C, (float*)dpred),
+    FRL_LAUNCH((mse_bwd_kernel<float, 1>), dim3(ew_grid(P * C)), dim3(256), 0, stream, (const float*)pred, (const float*)target, mask, gscale, stats, P, C, (float*)dpred),
+    FRL_LAUNCH((mse_bwd_kernel<bf16, 8>), dim3(ew_grid(P * (C / 8))), dim3(256), 0, stream, (const bf16*)pred, (const bf16*)target, mask, gscale, stats, P, C, (bf16*)dpred),
+    FRL_LAUNCH((mse_bwd_kernel<bf16, 1>), dim3(ew_grid(P * C)), dim3(256), 0, stream, (const bf16*)pred, (const bf16*)target, mask, gscale, stats, P, C, (bf16*)dpred))
 #undef VOK
   return frl_check_launch("mse_bwd");
 }
@@ -236,10 +236,10 @@ int frl_film_modulate_fwd(const void* h, const void* gamma, const void* beta, vo
   const int64_t hwc = HW * C;
 #define VOK(v) (hwc % (v) == 0)
   EW_DISPATCH(dtype, VOK,
-    hipLaunchKernelGGL((film_fwd_kernel<float, 4>), dim3(ew_grid(B * T * hwc / 4)), dim3(256), 0, stream, (const float*)h, (const float*)gamma, (const float*)beta, (float*)out, B, T, hwc),
-    hipLaunchKernelGGL((film_fwd_kernel<float, 1>), dim3(ew_grid(B * T * hwc)), dim3(256), 0, stream, (const float*)h, (const float*)gamma, (const float*)beta, (float*)out, B, T, hwc),
-    hipLaunchKernelGGL((film_fwd_kernel<bf16, 8>), dim3(ew_grid(B * T * hwc / 8)), dim3(256), 0, stream, (const bf16*)h, (const bf16*)gamma, (const bf16*)beta, (bf16*)out, B, T, hwc),
-    hipLaunchKernelGGL((film_fwd_kernel<bf16, 1>), dim3(ew_grid(B * T * hwc)), dim3(256), 0, stream, (const bf16*)h, (const bf16*)gamma, (const bf16*)beta, (bf16*)out, B, T, hwc))
+    FRL_LAUNCH((film_fwd_kernel<float, 4>), dim3(ew_grid(B * T * hwc / 4)), dim3(256), 0, stream, (const float*)h, (const float*)gamma, (const float*)beta, (float*)out, B, T, hwc),
+    FRL_LAUNCH((film_fwd_kernel<float, 1>), dim3(ew_grid(B * T * hwc)), dim3(256), 0, stream, (const float*)h, (const float*)gamma, (const float*)beta, (float*)out, B, T, hwc),
+    FRL_LAUNCH((film_fwd_kernel<bf16, 8>), dim3(ew_grid(B * T * hwc / 8)), dim3(256), 0, stream, (const bf16*)h, (const bf16*)gamma, (const bf16*)beta, (bf16*)out, B, T, hwc),
+    FRL_LAUNCH((film_fwd_kernel<bf16, 1>), dim3(ew_grid(B * T * hwc)), dim3(256), 0, stream, (const bf16*)h, (const bf16*)gamma, (const bf16*)beta, (bf16*)out, B, T, hwc))
   return frl_check_launch("film_modulate_fwd");
 }
 
@@ -247,10 +247,10 @@ int frl_film_modulate_bwd(const void* dout, const void* h, const void* gamma, vo
                           int64_t HW, int C, int dtype, hipStream_t stream) {
   const int64_t hwc = HW * C;
   EW_DISPATCH(dtype, VOK,
-    hipLaunchKernelGGL((film_bwd_kernel<float, 4>), dim3(ew_grid(B * hwc / 4)), dim3(256), 0, stream, (const float*)dout, (const float*)h, (const float*)gamma, (float*)dh, (float*)dgamma, (float*)dbeta, B, T, hwc),
-    hipLaunchKernelGGL((film_bwd_kernel<float, 1>), dim3(ew_grid(B * hwc)), dim3(256), 0, stream, (const float*)dout, (const float*)h, (const float*)gamma, (float*)dh, (float*)dgamma, (float*)dbeta, B, T, hwc),
-    hipLaunchKernelGGL((film_bwd_kernel<bf16, 8>), dim3(ew_grid(B * hwc / 8)), dim3(256), 0, stream, (const bf16*)dout, (const bf16*)h, (const bf16*)gamma, (bf16*)dh, (bf16*)dgamma, (bf16*)dbeta, B, T, hwc),
-    hipLaunchKernelGGL((film_bwd_kernel<bf16, 1>), dim3(ew_grid(B * hwc)), dim3(256), 0, stream, (const bf16*)dout, (const bf16*)h, (const bf16*)gamma, (bf16*)dh, (bf16*)dgamma, (bf16*)dbeta, B, T, hwc))
+    FRL_LAUNCH((film_bwd_kernel<float, 4>), dim3(ew_grid(B * hwc / 4)), dim3(256), 0, stream, (const float*)dout, (const float*)h, (const float*)gamma, (float*)dh, (float*)dgamma, (float*)dbeta, B, T, hwc),
+    FRL_LAUNCH((film_bwd_kernel<float, 1>), dim3(ew_grid(B * hwc)), dim3(256), 0, stream, (const float*)dout, (const float*)h, (const float*)gamma, (float*)dh, (float*)dgamma, (float*)dbeta, B, T, hwc),
+    FRL_LAUNCH((film_bwd_kernel<bf16, 8>), dim3(ew_grid(B * hwc / 8)), dim3(256), 0, stream, (const bf16*)dout, (const bf16*)h, (const bf16*)gamma, (bf16*)dh, (bf16*)dgamma, (bf16*)dbeta, B, T, hwc),
+    FRL_LAUNCH((film_bwd_kernel<bf16, 1>), dim3(ew_grid(B * hwc)), dim3(256), 0, stream, (const bf16*)dout, (const bf16*)h, (const bf16*)gamma, (bf16*)dh, (bf16*)dgamma, (bf16*)dbeta, B, T, hwc))
 #undef VOK
   return frl_check_launch("film_modulate_bwd");
 }
@@ -259,9 +259,9 @@ int frl_film_modulate_bwd(const void* dout, const void* h, const void* gamma, vo
 int frl_gate_blend_fwd(const void* smoothed, const void* residual, const void* gate_raw, float min_gate, void* out, void* gate_out,
                        int64_t n, int dtype, hipStream_t stream) {
   if (dtype == FRL_F32 && n % 4 == 0)
-    hipLaunchKernelGGL((gate_blend_fwd_kernel<float, 4>), dim3(ew_grid(n / 4)), dim3(256), 0, stream, (const float*)smoothed, (const float*)residual, (const float*)gate_raw, min_gate, (float*)out, (float*)gate_out, n / 4);
+    FRL_LAUNCH((gate_blend_fwd_kernel<float, 4>), dim3(ew_grid(n / 4)), dim3(256), 0, stream, (const float*)smoothed, (const float*)residual, (const float*)gate_raw, min_gate, (float*)out, (float*)gate_out, n / 4);
   else if (dtype == FRL_BF16 && n % 8 == 0)
-    hipLaunchKernelGGL((gate_blend_fwd_kernel<bf16, 8>), dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16*)smoothed, (const bf16*)residual, (const bf16*)gate_raw, min_gate, (bf16*)out, (bf16*)gate_out, n / 8);
+    FRL_LAUNCH((gate_blend_fwd_kernel<bf16, 8>), dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16*)smoothed, (const bf16*)residual, (const bf16*)gate_raw, min_gate, (bf16*)out, (bf16*)gate_out, n / 8);
   else return frl_fail(-2, "gate_blend: element count must be a multiple of the 16-byte vector width");
   return frl_check_launch("gate_blend_fwd");
 }
@@ -269,9 +269,9 @@ int frl_gate_blend_fwd(const void* smoothed, const void* residual, const void* g
 int frl_gate_blend_bwd(const void* dout, const void* dgate_ext, const void* residual, const void* gate_raw, float min_gate,
                        void* d_residual, void* d_gate_raw, int64_t n, int dtype, hipStream_t stream) {
   if (dtype == FRL_F32 && n % 4 == 0)
-    hipLaunchKernelGGL((gate_blend_bwd_kernel<float, 4>), dim3(ew_grid(n / 4)), dim3(256), 0, stream, (const float*)dout, (const float*)dgate_ext, (const float*)residual, (const float*)gate_raw, min_gate, (float*)d_residual, (float*)d_gate_raw, n / 4);
+    FRL_LAUNCH((gate_blend_bwd_kernel<float, 4>), dim3(ew_grid(n / 4)), dim3(256), 0, stream, (const float*)dout, (const float*)dgate_ext, (const float*)residual, (const float*)gate_raw, min_gate, (float*)d_residual, (float*)d_gate_raw, n / 4);
   else if (dtype == FRL_BF16 && n % 8 == 0)
-    hipLaunchKernelGGL((gate_blend_bwd_kernel<bf16, 8>), dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16*)dout, (const bf16*)dgate_ext, (const bf16*)residual, (const bf16*)gate_raw, min_gate, (bf16*)d_residual, (bf16*)d_gate_raw, n / 8);
+    FRL_LAUNCH((gate_blend_bwd_kernel<bf16, 8>), dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16*)dout, (const bf16*)dgate_ext, (const bf16*)residual, (const bf16*)gate_raw, min_gate, (bf16*)d_residual, (bf16*)d_gate_raw, n / 8);
   else return frl_fail(-2, "gate_blend: element count must be a multiple of the 16-byte vector width");
   return frl_check_launch("gate_blend_bwd");
 }
@@ -279,18 +279,18 @@ int frl_gate_blend_bwd(const void* dout, const void* dgate_ext, const void* resi
 // tile [B][T][HWC] -> out [B][HWC] (mean over time)
 int frl_mean_time_fwd(const void* tile, void* out, int64_t B, int T, int64_t HWC, int dtype, hipStream_t stream) {
   if (dtype == FRL_F32 && HWC % 4 == 0)
-    hipLaunchKernelGGL((mean_time_kernel<float, 4>), dim3(ew_grid(B * HWC / 4)), dim3(256), 0, stream, (const float*)tile, (float*)out, B, T, HWC);
+    FRL_LAUNCH((mean_time_kernel<float, 4>), dim3(ew_grid(B * HWC / 4)), dim3(256), 0, stream, (const float*)tile, (float*)out, B, T, HWC);
   else if (dtype == FRL_BF16 && HWC % 8 == 0)
-    hipLaunchKernelGGL((mean_time_kernel<bf16, 8>), dim3(ew_grid(B * HWC / 8)), dim3(256), 0, stream, (const bf16*)tile, (bf16*)out, B, T, HWC);
+    FRL_LAUNCH((mean_time_kernel<bf16, 8>), dim3(ew_grid(B * HWC / 8)), dim3(256), 0, stream, (const bf16*)tile, (bf16*)out, B, T, HWC);
   else return frl_fail(-2, "mean_time: H*W*C must be a multiple of the 16-byte vector width");
   return frl_check_launch("mean_time_fwd");
 }
 
-int frl_add(const void* a, const void* b, void* out, int64_t n, int dtype, hipStream_t stream) {
+int frl_add(const void* a, const void* b, float scale_b, void* out, int64_t n, int dtype, hipStream_t stream) {
   if (dtype == FRL_F32 && n % 4 == 0)
-    hipLaunchKernelGGL((add_kernel<float, 4>), dim3(ew_grid(n / 4)), dim3(256), 0, stream, (const float*)a, (const float*)b, (float*)out, n / 4);
+    FRL_LAUNCH((add_kernel<float, 4>), dim3(ew_grid(n / 4)), dim3(256), 0, stream, (const float*)a, (const float*)b, scale_b, (float*)out, n / 4);
   else if (dtype == FRL_BF16 && n % 8 == 0)
-    hipLaunchKernelGGL((add_kernel<bf16, 8>), dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16*)a, (const bf16*)b, (bf16*)out, n / 8);
+    FRL_LAUNCH((add_kernel<bf16, 8>), dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16*)a, (const bf16*)b, scale_b, (bf16*)out, n / 8);
   else return frl_fail(-2, "add: element count must be a multiple of the 16-byte vector width");
   return frl_check_launch("add");
 }

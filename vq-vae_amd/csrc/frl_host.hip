@@ -4,6 +4,7 @@
 #include <stdio.h>
 
 static thread_local char g_err[512] = "";
+thread_local hipError_t g_frl_pending = hipSuccess;
 
 int frl_fail(int code, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "unknown error");
@@ -11,7 +12,8 @@ int frl_fail(int code, const char* msg) {
 }
 
 int frl_check_launch(const char* what) {
-  hipError_t e = hipGetLastError();
+  hipError_t e = g_frl_pending;
+  g_frl_pending = hipSuccess;
   if (e != hipSuccess) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
     return -100 - (int)e;

@@ -7,6 +7,18 @@
 int frl_fail(int code, const char* msg);           // records thread-local message, returns code
 int frl_check_launch(const char* what);            // hipGetLastError() -> 0 or negative code
 
+// Kernel launch with per-launch error capture.  hipGetLastError() is sticky per thread and may hold a stale error from
+// runtime initialisation done elsewhere in the process (e.g. by PyTorch), so the state is cleared before every launch
+// and the first failure of a call is parked in g_frl_pending until frl_check_launch() reports it.
+extern thread_local hipError_t g_frl_pending;
+#define FRL_LAUNCH(...)                                                     \
+  do {                                                                      \
+    (void)hipGetLastError();                                                \
+    hipLaunchKernelGGL(__VA_ARGS__);                                        \
+    hipError_t _le = hipGetLastError();                                     \
+    if (_le != hipSuccess && g_frl_pending == hipSuccess) g_frl_pending = _le; \
+  } while (0)
+
 #define FRL_HIP(expr)                                            \
   do {                                                           \
     hipError_t _e = (expr);                                      \

@@ -167,12 +167,12 @@ static int gn_fwd_impl(const void* x, const float* gamma, const float* beta, voi
   const int vpr = C / V;
   const int rpi = 256 / vpr > 0 ? 256 / vpr : 1;
   const size_t lds = (size_t)2 * rpi * C * sizeof(float);
-  hipLaunchKernelGGL((gn_reduce_kernel<T, V, 0>), dim3(B), dim3(256), lds, st, (const T*)x, (const T*)nullptr, gamma, beta,
+  FRL_LAUNCH((gn_reduce_kernel<T, V, 0>), dim3(B), dim3(256), lds, st, (const T*)x, (const T*)nullptr, gamma, beta,
                      (const float*)nullptr, (const float*)nullptr, HW, C, G, eps, 0, mean, rstd, (float*)nullptr);
   const int64_t tv = (int64_t)B * HW * vpr;
   int64_t grid = (tv + 255) / 256;
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL((gn_apply_kernel<T, V>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)x, gamma, beta,
+  FRL_LAUNCH((gn_apply_kernel<T, V>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)x, gamma, beta,
                      (const float*)mean, (const float*)rstd, (T*)y, tv, HW, C, G, relu);
   return frl_check_launch("groupnorm_fwd");
 }
@@ -187,15 +187,15 @@ static int gn_bwd_impl(const void* dy, const void* x, const float* gamma, const 
   float* sdy = ws;                         // [B][C]
   float* sdyx = ws + (size_t)B * C;        // [B][C]
   float* grp = ws + (size_t)2 * B * C;     // [B][G][2]
-  hipLaunchKernelGGL((gn_reduce_kernel<T, V, 1>), dim3(B), dim3(256), lds, st, (const T*)x, (const T*)dy, gamma, beta, mean,
+  FRL_LAUNCH((gn_reduce_kernel<T, V, 1>), dim3(B), dim3(256), lds, st, (const T*)x, (const T*)dy, gamma, beta, mean,
                      rstd, HW, C, G, 0.f, relu, sdy, sdyx, grp);
   const int64_t tv = (int64_t)B * HW * vpr;
   int64_t grid = (tv + 255) / 256;
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)x, (const T*)dy, gamma,
+  FRL_LAUNCH((gn_bwd_apply_kernel<T, V>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)x, (const T*)dy, gamma,
                      beta, mean, rstd, (const float*)grp, (T*)dx, tv, HW, C, G, relu);
-  hipLaunchKernelGGL(colsum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)sdy, B, C, dbeta);
-  hipLaunchKernelGGL(colsum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)sdyx, B, C, dgamma);
+  FRL_LAUNCH(colsum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)sdy, B, C, dbeta);
+  FRL_LAUNCH(colsum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)sdyx, B, C, dgamma);
   return frl_check_launch("groupnorm_bwd");
 }
 

@@ -116,7 +116,7 @@ static int launch_pw(const void* x, const void* xmask, int mask_act, const float
   int64_t grid = (ngroups + 3) / 4;
   if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, (const T*)x, (const T*)xmask, mask_act, w,
+  FRL_LAUNCH(kern, dim3((unsigned)grid), dim3(256), lds, st, (const T*)x, (const T*)xmask, mask_act, w,
                      so, si, bias, (T*)y, P, Cin, Cout, act);
   return frl_check_launch("pw_conv");
 }

@@ -210,7 +210,7 @@ static int launch_wgrad(const void* dy, const void* ymask, int mask_act, const v
   const size_t lds = (size_t)WG_KP * ((OBW * 64 + 8) + (IB * 16 + 8)) * sizeof(T);
   auto kern = pw_wgrad_kernel<T, OBW, IB>;
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, (const T*)dy, (const T*)ymask, mask_act, (const T*)x, ws,
+  FRL_LAUNCH(kern, dim3(nwg), dim3(256), lds, st, (const T*)dy, (const T*)ymask, mask_act, (const T*)x, ws,
                      P, Cout, Cin, rows, HW, Tn, toff, use_tr);
   return frl_check_launch("pw_wgrad");
 }
@@ -266,7 +266,7 @@ int frl_conv_tap_bwd_weight(const void* dy, const void* y, int act, const void* 
   else return frl_fail(-2, "bwd_weight: bad dtype");
   if (rc) return rc;
   const int64_t n = (int64_t)Cout * Cin + Cout;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)ws,
+  FRL_LAUNCH(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)ws,
                      wgrad_nwg(P), Cout, Cin, dw, dso, dsi, dbias, (flags & 2) ? 1 : 0);
   return frl_check_launch("slab_reduce");
 }

@@ -312,9 +312,9 @@ static int smooth_dispatch(bool fwd, const void* a0, const void* a1, const void*
   if (grid > 8192) grid = 8192;
 #define SM_CASE(RR)                                                                                                     \
   if (R == RR) {                                                                                                        \
-    if (fwd) hipLaunchKernelGGL((smooth_fwd_kernel<T, V, RR>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)a0, (const T*)a1, \
+    if (fwd) FRL_LAUNCH((smooth_fwd_kernel<T, V, RR>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)a0, (const T*)a1, \
                                 (const T*)a2, (T*)o0, (T*)o1, (T*)o2, (T*)o3, B, H, W, C, dil, tpp);                     \
-    else hipLaunchKernelGGL((smooth_bwd_kernel<T, V, RR>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)a0, (const T*)a1,      \
+    else FRL_LAUNCH((smooth_bwd_kernel<T, V, RR>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)a0, (const T*)a1,      \
                             (const T*)a2, (const T*)a3, (T*)o0, (T*)o1, (T*)o2, B, H, W, C, dil, tpp);                   \
     return frl_check_launch("edge_smooth_stencil");                                                                     \
   }
@@ -328,18 +328,18 @@ extern "C" {
 // x [B][H][W][C] -> g [B][H][W][2C] = cat[sobel_x(x), sobel_y(x)]
 int frl_sobel_fwd(const void* x, void* g, int B, int H, int W, int C, int dtype, hipStream_t stream) {
   if (dtype == FRL_F32 && C % 4 == 0)
-    hipLaunchKernelGGL((sobel_fwd_kernel<float, 4>), dim3(st_grid((int64_t)B * H * W * (C / 4))), dim3(256), 0, stream, (const float*)x, (float*)g, B, H, W, C);
+    FRL_LAUNCH((sobel_fwd_kernel<float, 4>), dim3(st_grid((int64_t)B * H * W * (C / 4))), dim3(256), 0, stream, (const float*)x, (float*)g, B, H, W, C);
   else if (dtype == FRL_BF16 && C % 8 == 0)
-    hipLaunchKernelGGL((sobel_fwd_kernel<bf16, 8>), dim3(st_grid((int64_t)B * H * W * (C / 8))), dim3(256), 0, stream, (const bf16*)x, (bf16*)g, B, H, W, C);
+    FRL_LAUNCH((sobel_fwd_kernel<bf16, 8>), dim3(st_grid((int64_t)B * H * W * (C / 8))), dim3(256), 0, stream, (const bf16*)x, (bf16*)g, B, H, W, C);
   else return frl_fail(-2, "sobel: C must be a multiple of 8 (bf16) / 4 (f32)");
   return frl_check_launch("sobel_fwd");
 }
 
 int frl_sobel_bwd(const void* dg, void* dx, int B, int H, int W, int C, int dtype, hipStream_t stream) {
   if (dtype == FRL_F32 && C % 4 == 0)
-    hipLaunchKernelGGL((sobel_bwd_kernel<float, 4>), dim3(st_grid((int64_t)B * H * W * (C / 4))), dim3(256), 0, stream, (const float*)dg, (float*)dx, B, H, W, C);
+    FRL_LAUNCH((sobel_bwd_kernel<float, 4>), dim3(st_grid((int64_t)B * H * W * (C / 4))), dim3(256), 0, stream, (const float*)dg, (float*)dx, B, H, W, C);
   else if (dtype == FRL_BF16 && C % 8 == 0)
-    hipLaunchKernelGGL((sobel_bwd_kernel<bf16, 8>), dim3(st_grid((int64_t)B * H * W * (C / 8))), dim3(256), 0, stream, (const bf16*)dg, (bf16*)dx, B, H, W, C);
+    FRL_LAUNCH((sobel_bwd_kernel<bf16, 8>), dim3(st_grid((int64_t)B * H * W * (C / 8))), dim3(256), 0, stream, (const bf16*)dg, (bf16*)dx, B, H, W, C);
   else return frl_fail(-2, "sobel: C must be a multiple of 8 (bf16) / 4 (f32)");
   return frl_check_launch("sobel_bwd");
 }

@@ -214,9 +214,9 @@ static int launch_tcn_bwd(const void* x, const void* dy, const float* wc, const 
   auto kern = tcn_block_bwd_kernel<T, NFI, MBO>;
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned grid = tcn_bwd_grid(a.npix);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, (const T*)x, (const T*)dy, wc, bc, gw, gb, wg, bg, wp, bp, (T*)dconv, (T*)dgpre,
+  FRL_LAUNCH(kern, dim3(grid), dim3(256), lds, st, (const T*)x, (const T*)dy, wc, bc, gw, gb, wg, bg, wp, bp, (T*)dconv, (T*)dgpre,
                      (T*)normed, (T*)dres, ws, a);
-  hipLaunchKernelGGL(tcn_slab_reduce_kernel, dim3((2 * a.Cout + 255) / 256), dim3(256), 0, st, (const float*)ws, (int)grid, a.Cout, dgamma, dbeta);
+  FRL_LAUNCH(tcn_slab_reduce_kernel, dim3((2 * a.Cout + 255) / 256), dim3(256), 0, st, (const float*)ws, (int)grid, a.Cout, dgamma, dbeta);
   return frl_check_launch("tcn_block_bwd");
 }
 

@@ -172,7 +172,7 @@ static int launch_tcn_fwd(const void* x, const float* wc, const float* bc, const
   if (lds > 160 * 1024) return frl_fail(-3, "tcn_block_fwd: weights exceed LDS");
   auto kern = tcn_block_fwd_kernel<T, NFI, MBO>;
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(tcn_grid(a.npix)), dim3(256), lds, st, (const T*)x, wc, bc, gw, gb, wg, bg, wp, bp, (T*)y, a);
+  FRL_LAUNCH(kern, dim3(tcn_grid(a.npix)), dim3(256), lds, st, (const T*)x, wc, bc, gw, gb, wg, bg, wp, bp, (T*)y, a);
   return frl_check_launch("tcn_block_fwd");
 }
 
@@ -184,7 +184,7 @@ static int launch_tconv3(const void* x, const float* w, int64_t so, int64_t si, 
   if (lds > 160 * 1024) return frl_fail(-3, "tconv3: weights exceed LDS");
   auto kern = tconv3_kernel<T, NFI, MBO, NFP>;
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(tcn_grid(a.npix)), dim3(256), lds, st, (const T*)x, w, so, si, rev, (const T*)r, (const T*)r2, wp, pso,
+  FRL_LAUNCH(kern, dim3(tcn_grid(a.npix)), dim3(256), lds, st, (const T*)x, w, so, si, rev, (const T*)r, (const T*)r2, wp, pso,
                      psi, Cp, (T*)y, a);
   return frl_check_launch("tconv3");
 }

@@ -394,7 +394,7 @@ __global__ void vq_code_reduce_kernel(const float* __restrict__ slab, int nslab,
   for (int w = 0; w < nslab; ++w) s += slab[(int64_t)w * K * d + i];
   if (sums_out) sums_out[i] = s;
   if (gE) {
-    const float ce = ce_base * (gscale ? gscale[0] : 1.f);
+    const float ce = ce_base * (gscale ? gscale[1] : 1.f);
     const float ev = to_f32(from_f32<T>(E[i]));
     gE[i] = ce * ((float)counts[i / d] * ev - s);
   }
@@ -470,18 +470,18 @@ static int launch_vq(const void* z, const float* E, int64_t N, int K, int d, int
   float* en = (float*)(ws + L.en);
   // zero header, fixup counters (everything between hdr and hist)
   FRL_HIP(hipMemsetAsync(ws, 0, L.hist, st));
-  hipLaunchKernelGGL((vq_prep_kernel<T>), dim3((K + 255) / 256), dim3(256), 0, st, E, K, d, en, hdr);
+  FRL_LAUNCH((vq_prep_kernel<T>), dim3((K + 255) / 256), dim3(256), 0, st, E, K, d, en, hdr);
   const size_t lds = (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc * 4 + (size_t)K * 4;
   if (lds > 160 * 1024) return frl_fail(-3, "vq_assign: LDS budget exceeded (K too large for histogram)");
   auto kern = vq_assign_kernel<T, NF, VQ_NT>;
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(L.grid), dim3(256), lds, st, (const T*)z, E, en, hdr, N, K, d, Kc, idx, (T*)zq,
+  FRL_LAUNCH(kern, dim3(L.grid), dim3(256), lds, st, (const T*)z, E, en, hdr, N, K, d, Kc, idx, (T*)zq,
                      (float*)(ws + L.partial), (int32_t*)(ws + L.hist));
   const int64_t rpw = ((N + VQ_FIX_WAVES - 1) / VQ_FIX_WAVES + 63) / 64 * 64;
-  hipLaunchKernelGGL((vq_fixup_kernel<T>), dim3(VQ_FIX_WAVES / 4), dim3(256), (size_t)4 * d * sizeof(double), st,
+  FRL_LAUNCH((vq_fixup_kernel<T>), dim3(VQ_FIX_WAVES / 4), dim3(256), (size_t)4 * d * sizeof(double), st,
                      (const T*)z, E, N, K, d, rpw, idx, (T*)zq, (float*)(ws + L.partial_fix),
                      (int32_t*)(ws + L.counts_fix), (int32_t*)(ws + L.namb));
-  hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)(ws + L.partial),
+  FRL_LAUNCH(vq_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)(ws + L.partial),
                      L.grid * 4 + VQ_FIX_WAVES, (const int32_t*)(ws + L.hist), L.grid, K,
                      (const int32_t*)(ws + L.counts_fix), (const int32_t*)(ws + L.namb), N, counts, stats);
   return frl_check_launch("vq_assign");
@@ -526,8 +526,8 @@ int frl_vq_assign_fwd(const void* z, const float* E, int64_t N, int K, int d, in
   return frl_fail(-2, "vq_assign: bad dtype");
 }
 
-// g_z = g_out + gscale * beta * 2/(N d) * (z - e_idx);  g_E[k] = gscale * 2/(N d) * (n_k e_k - sum_{idx=k} z)
-// gscale: device scalar (upstream gradient of vq_loss), may be null (=1).  g_out may be null (=0).
+// g_z = g_out + gscale[0] * beta * 2/(N d) * (z - e_idx);  g_E[k] = gscale[1] * 2/(N d) * (n_k e_k - sum_{idx=k} z)
+// gscale: device float[2] = upstream gradients of {L_commit, L_codebook}, may be null (= {1, 1}).  g_out may be null (=0).
 // g_z / g_E may be null to skip.  sums_out (optional, [K][d] f32) receives the per-code sums of z.
 int frl_vq_bwd(const void* g_out, const void* z, const float* E, const int32_t* idx, const int32_t* counts,
                const float* gscale, float beta, int64_t N, int K, int d, void* g_z_out, float* g_E_out,
@@ -542,16 +542,16 @@ int frl_vq_bwd(const void* g_out, const void* z, const float* E, const int32_t* 
   if (dtype == FRL_F32) {
     auto kern = vq_bwd_kernel<float>;
     if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(VQ_BWD_WGS), dim3(256), lds, stream, (const float*)g_out, (const float*)z, E, idx, gscale,
+    FRL_LAUNCH(kern, dim3(VQ_BWD_WGS), dim3(256), lds, stream, (const float*)g_out, (const float*)z, E, idx, gscale,
                        cz, N, K, d, Kc, rows, (float*)g_z_out, slab);
-    hipLaunchKernelGGL((vq_code_reduce_kernel<float>), dim3((unsigned)(((int64_t)K * d + 255) / 256)), dim3(256), 0, stream,
+    FRL_LAUNCH((vq_code_reduce_kernel<float>), dim3((unsigned)(((int64_t)K * d + 255) / 256)), dim3(256), 0, stream,
                        (const float*)slab, VQ_BWD_WGS, E, counts, gscale, ce, K, d, g_E_out, sums_out);
   } else if (dtype == FRL_BF16) {
     auto kern = vq_bwd_kernel<bf16>;
     if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(VQ_BWD_WGS), dim3(256), lds, stream, (const bf16*)g_out, (const bf16*)z, E, idx, gscale,
+    FRL_LAUNCH(kern, dim3(VQ_BWD_WGS), dim3(256), lds, stream, (const bf16*)g_out, (const bf16*)z, E, idx, gscale,
                        cz, N, K, d, Kc, rows, (bf16*)g_z_out, slab);
-    hipLaunchKernelGGL((vq_code_reduce_kernel<bf16>), dim3((unsigned)(((int64_t)K * d + 255) / 256)), dim3(256), 0, stream,
+    FRL_LAUNCH((vq_code_reduce_kernel<bf16>), dim3((unsigned)(((int64_t)K * d + 255) / 256)), dim3(256), 0, stream,
                        (const float*)slab, VQ_BWD_WGS, E, counts, gscale, ce, K, d, g_E_out, sums_out);
   } else return frl_fail(-2, "vq_bwd: bad dtype");
   return frl_check_launch("vq_bwd");
@@ -561,7 +561,7 @@ int frl_vq_bwd(const void* g_out, const void* z, const float* E, const int32_t* 
 // (both produced by frl_vq_assign_fwd / frl_vq_bwd(sums_out)).  Updates ema_count, ema_sum, E in place.
 int frl_vq_ema_update(const float* sums, const int32_t* counts, int K, int d, float decay, float eps, float* ema_count,
                       float* ema_sum, float* E, hipStream_t stream) {
-  hipLaunchKernelGGL(vq_ema_kernel, dim3(1), dim3(256), 0, stream, sums, counts, K, d, decay, eps, ema_count, ema_sum, E);
+  FRL_LAUNCH(vq_ema_kernel, dim3(1), dim3(256), 0, stream, sums, counts, K, d, decay, eps, ema_count, ema_sum, E);
   return frl_check_launch("vq_ema_update");
 }
 

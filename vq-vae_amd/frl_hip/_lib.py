@@ -48,7 +48,7 @@ SIGNATURES = {
     "frl_gate_blend_fwd": (c_int, [P, P, P, F, P, P, L, I, P]),
     "frl_gate_blend_bwd": (c_int, [P, P, P, P, F, P, P, L, I, P]),
     "frl_mean_time_fwd": (c_int, [P, P, L, I, L, I, P]),
-    "frl_add": (c_int, [P, P, P, L, I, P]),
+    "frl_add": (c_int, [P, P, F, P, L, I, P]),
     "frl_conv3x3_fwd": (c_int, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "frl_conv3x3_bwd_data": (c_int, [P, P, I, P, P, I, I, I, I, I, I, P]),
     "frl_conv3x3_bwd_weight_workspace_bytes": (S, [I, I, I, I, I]),

@@ -1,0 +1,240 @@
+"""torch.autograd.Function wrappers: PyTorch carries the autograd graph, every forward/backward body is a HIP kernel.
+
+Tensors are NHWC rows ([..., C] contiguous) in the compute dtype (float32 parity mode / bfloat16 performance mode);
+parameters stay float32 in the reference's layouts and receive float32 gradients.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import ops
+from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID  # noqa: F401
+
+
+def _c(t: Optional[torch.Tensor]):
+    return None if t is None else (t if t.is_contiguous() else t.contiguous())
+
+
+class Conv1x1Fn(Function):
+    """y = act(x W^T + b) over rows; W [Cout, Cin(,1,1)]."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, act):
+        y = ops.conv1x1_fwd(x, w, bias, act)
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = _c(dy)
+        dx = ops.conv1x1_bwd_data(dy, w, y, ctx.act) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = ops.conv1x1_bwd_weight(dy, x, y, ctx.act, want_bias=ctx.has_bias)
+            dw = dw.reshape(w.shape)
+        return dx, dw, db, None
+
+
+class Conv3x3Fn(Function):
+    """y = act(conv3x3_pad1(x, W) + b); x [B,H,W,Cin], W [Cout,Cin,3,3]."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, act):
+        y = ops.conv3x3_fwd(x, w, bias, act)
+        ctx.act = act
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = _c(dy)
+        dx = ops.conv3x3_bwd_data(dy, w, y, ctx.act) if ctx.needs_input_grad[0] else None
+        dw, db = ops.conv3x3_bwd_weight(dy, x, y, ctx.act)
+        return dx, dw, db, None
+
+
+class GroupNormFn(Function):
+    """nn.GroupNorm over [B, ..., C] rows with optional fused ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, relu):
+        y, mean, rstd = ops.groupnorm_fwd(x, gamma, beta, groups, eps, relu)
+        ctx.groups, ctx.relu = groups, relu
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        dx, dg, db = ops.groupnorm_bwd(_c(dy), x, gamma, beta, mean, rstd, ctx.groups, ctx.relu)
+        return dx, dg, db, None, None, None
+
+
+class SobelFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.sobel_fwd(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dg):
+        return ops.sobel_bwd(_c(dg))
+
+
+class EdgeSmoothFn(Function):
+    """(x, a_logit, b_logit) -> (smoothed, residual = x - smoothed)."""
+
+    @staticmethod
+    def forward(ctx, x, a_logit, b_logit, rank, dil):
+        sm, res, a_soft, b_soft = ops.edge_smooth_fwd(x, a_logit, b_logit, rank, dil)
+        ctx.rank, ctx.dil = rank, dil
+        ctx.save_for_backward(x, a_soft, b_soft)
+        return sm, res
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_sm, d_res):
+        x, a_soft, b_soft = ctx.saved_tensors
+        d_sm, d_res = _c(d_sm), _c(d_res)
+        d_tot = ops.add(d_sm, d_res, -1.0)                # residual = x - smoothed
+        dx, da, db = ops.edge_smooth_bwd(d_tot, x, a_soft, b_soft, ctx.rank, ctx.dil)
+        dx = ops.add(dx, d_res, 1.0)
+        return dx, da, db, None, None
+
+
+class GateBlendFn(Function):
+    """(smoothed, residual, gate_raw) -> (out = smoothed + clamp(gate) * residual, gate)."""
+
+    @staticmethod
+    def forward(ctx, smoothed, residual, gate_raw, min_gate):
+        out, gate = ops.gate_blend_fwd(smoothed, residual, gate_raw, min_gate)
+        ctx.min_gate = min_gate
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(residual, gate_raw)
+        return out, gate
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout, dgate):
+        residual, gate_raw = ctx.saved_tensors
+        if dout is None:
+            dout = torch.zeros_like(residual)
+        dout = _c(dout)
+        dres, dgraw = ops.gate_blend_bwd(dout, _c(dgate), residual, gate_raw, ctx.min_gate)
+        return dout, dres, dgraw, None
+
+
+class TcnBlockFn(Function):
+    """Fused GatedResidualBlock on x [B,T,HW..,Cin]."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, dilation, groups, eps):
+        pw = None if proj_w is None else proj_w.reshape(proj_w.shape[0], proj_w.shape[1])
+        y = ops.tcn_block_fwd(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, pw, proj_b, dilation, groups, eps)
+        ctx.cfg = (dilation, groups, eps)
+        ctx.save_for_backward(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b = ctx.saved_tensors
+        dilation, groups, eps = ctx.cfg
+        pw = None if proj_w is None else proj_w.reshape(proj_w.shape[0], proj_w.shape[1])
+        g = ops.tcn_block_bwd(x, _c(dy), conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, pw, proj_b, dilation, groups, eps)
+        dpw = g["proj_w"].reshape(proj_w.shape) if proj_w is not None else None
+        return (g["dx"] if ctx.needs_input_grad[0] else None, g["conv_w"], g["conv_b"], g["gn_w"], g["gn_b"], g["gate_w"],
+                g["gate_b"], dpw, g.get("proj_b"), None, None, None)
+
+
+class FilmFn(Function):
+    """z[b,t,p,c] = gamma[b,p,c] * h[b,t,p,c] + beta[b,p,c]."""
+
+    @staticmethod
+    def forward(ctx, h, gamma, beta):
+        ctx.save_for_backward(h, gamma)
+        return ops.film_modulate_fwd(h, gamma, beta)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        h, gamma = ctx.saved_tensors
+        return ops.film_modulate_bwd(_c(dout), h, gamma)
+
+
+class VQFn(Function):
+    """(z [N,d], codebook [K,d]) -> (z_q [straight-through], L_codebook, L_commit, perplexity, idx, counts).
+
+    L_codebook = mean((sg[z] - z_q)^2) and L_commit = mean((z - sg[z_q])^2) are numerically equal in the forward;
+    they are separate outputs so that autograd routes their upstream gradients to the codebook and to z respectively.
+    """
+
+    @staticmethod
+    def forward(ctx, z, codebook):
+        idx, zq, stats, counts = ops.vq_assign(z, codebook)
+        d = z.shape[-1]
+        n = z.numel() // d
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(z, codebook, idx, counts)
+        mse = stats[0] / float(n * d)
+        ctx.mark_non_differentiable(idx, counts)
+        return zq, mse, mse.clone(), stats[1].clone(), idx, counts
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_zq, g_cb, g_cm, g_perp, g_idx, g_counts):
+        z, codebook, idx, counts = ctx.saved_tensors
+        gs = torch.zeros(2, dtype=torch.float32, device=z.device)
+        if g_cm is not None:
+            gs[0] = g_cm
+        if g_cb is not None:
+            gs[1] = g_cb
+        gz, ge, _ = ops.vq_bwd(_c(g_zq), z, codebook, idx, counts, gs, 1.0,
+                               want_gz=ctx.needs_input_grad[0], want_ge=ctx.needs_input_grad[1])
+        return gz, ge
+
+
+class MseFn(Function):
+    """Masked mean squared error -> f32 scalar tensor."""
+
+    @staticmethod
+    def forward(ctx, pred, target, mask):
+        stats = ops.mse_fwd(pred, target, mask)
+        ctx.save_for_backward(pred, target, mask, stats)
+        return stats[0].clone()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        pred, target, mask, stats = ctx.saved_tensors
+        return ops.mse_bwd(pred, target, mask, g.reshape(1).float().contiguous(), stats), None, None
+
+
+def conv1x1(x, w, bias=None, act=ACT_NONE):
+    return Conv1x1Fn.apply(x, w, bias, act)
+
+
+def conv3x3(x, w, bias=None, act=ACT_NONE):
+    return Conv3x3Fn.apply(x, w, bias, act)
+
+
+def group_norm(x, gamma, beta, groups, eps=1e-5, relu=False):
+    return GroupNormFn.apply(x, gamma, beta, groups, eps, relu)
+
+
+def mse_loss(pred, target, mask=None):
+    """mask: [rows] / [B,H,W] bool or uint8 (True = valid) broadcast over channels, or None."""
+    if mask is not None:
+        mask = mask.reshape(-1).to(torch.uint8).contiguous()
+    return MseFn.apply(pred, target, mask)

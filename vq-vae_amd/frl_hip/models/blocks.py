@@ -1,0 +1,274 @@
+"""Building blocks with the reference's module / parameter names, computing through HIP kernels (NHWC rows).
+
+Each class mirrors one reference module so that `state_dict()` keys and tensor shapes are identical and reference
+checkpoints load unchanged:
+  Conv2DEncoder            frl/models/conv2d_encoder.py:19-159
+  EdgeAwareSmoothingConv2D frl/models/spatial.py:165-343
+  GatedResidualBlock/TCNEncoder  frl/models/tcn.py:24-302
+  FiLMLayer                frl/models/conditioning.py:16-102
+  Conv2DHead (decoder)     frl/models/heads.py:128-198
+All `forward` methods take and return NHWC tensors in the compute dtype; layout conversion from the reference's
+NCHW API happens once at the model boundary (models/representation.py).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Union
+
+import torch
+import torch.nn as nn
+
+from .. import functional as Fh
+from ..functional import ACT_NONE, ACT_RELU, ACT_SIGMOID
+
+
+def _kaiming_uniform_(w: torch.Tensor, fan_in: int):
+    bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0  # kaiming_uniform_(a=sqrt(5)) == U(+-1/sqrt(fan_in))
+    with torch.no_grad():
+        w.uniform_(-bound, bound)
+
+
+class _Marker(nn.Module):
+    """Parameter-free placeholder that keeps nn.Sequential indices aligned with the reference (ReLU / Sigmoid / Dropout)."""
+
+    def __init__(self, kind: str, p: float = 0.0):
+        super().__init__()
+        self.kind, self.p = kind, p
+
+    def extra_repr(self):
+        return f"{self.kind}" + (f", p={self.p}" if self.kind.startswith("dropout") else "")
+
+
+class Conv2dParams(nn.Module):
+    """Holds nn.Conv2d-shaped parameters (weight [Co,Ci,k,k], optional bias); compute is done by the parent."""
+
+    def __init__(self, cin: int, cout: int, k: int = 1, bias: bool = True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.k = cin, cout, k
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+        _kaiming_uniform_(self.weight, cin * k * k)
+        if bias:
+            _kaiming_uniform_(self.bias, cin * k * k)
+
+    def forward(self, x, act: int = ACT_NONE):
+        if self.k == 1:
+            return Fh.conv1x1(x, self.weight, self.bias, act)
+        if self.k == 3:
+            return Fh.conv3x3(x, self.weight, self.bias, act)
+        raise NotImplementedError("only 1x1 and 3x3 (pad 1) convolutions are on the hot path")
+
+
+class Conv1dParams(nn.Module):
+    """nn.Conv1d-shaped parameters (weight [Co,Ci,k], bias)."""
+
+    def __init__(self, cin: int, cout: int, k: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k))
+        self.bias = nn.Parameter(torch.empty(cout))
+        _kaiming_uniform_(self.weight, cin * k)
+        _kaiming_uniform_(self.bias, cin * k)
+
+
+class GroupNormParams(nn.Module):
+    def __init__(self, groups: int, channels: int, eps: float = 1e-5):
+        super().__init__()
+        self.num_groups, self.num_channels, self.eps = groups, channels, eps
+        self.weight = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+
+    def forward(self, x, relu: bool = False):
+        return Fh.group_norm(x, self.weight, self.bias, self.num_groups, self.eps, relu)
+
+
+def channel_dropout(x: torch.Tensor, p: float, training: bool, group_rows: int) -> torch.Tensor:
+    """Dropout2d / Dropout1d semantics on NHWC rows: zero whole channels per sample (group of `group_rows` rows).
+
+    p == 0 or eval -> identity (the parity configuration).  p > 0 in training is not implemented in HIP yet and is
+    refused rather than silently skipped.
+    """
+    if not training or p <= 0.0:
+        return x
+    raise NotImplementedError("channel dropout with p > 0 in training mode: configure dropout 0.0 (see DESIGN.md)")
+
+
+class Conv2DEncoder(nn.Module):
+    """[conv1x1(bias=False) -> GroupNorm -> ReLU -> Dropout2d] x (L-1) -> conv1x1 -> GroupNorm  (conv2d_encoder.py:100-127)."""
+
+    def __init__(self, in_channels: int, channels: Sequence[int], kernel_size=1, padding=0,
+                 dropout_rate: Union[float, Sequence[float]] = 0.0, num_groups: Union[int, Sequence[int]] = 8,
+                 input_dropout_rate: float = 0.0):
+        super().__init__()
+        channels = list(channels)
+        n = len(channels)
+        assert n > 0
+        ks = [kernel_size] * n if isinstance(kernel_size, int) else list(kernel_size)
+        if any(k != 1 for k in ks):
+            raise NotImplementedError("type encoder kernel_size must be 1 on the HIP path")
+        dr = [dropout_rate] * n if isinstance(dropout_rate, (int, float)) else list(dropout_rate)
+        ng = [num_groups] * n if isinstance(num_groups, int) else list(num_groups)
+        self.in_channels, self.out_channels = in_channels, channels[-1]
+        self.input_dropout = _Marker("dropout2d", input_dropout_rate)
+        layers: List[nn.Module] = []
+        prev = in_channels
+        for i, (co, drop, g) in enumerate(zip(channels, dr, ng)):
+            last = i == n - 1
+            layers.append(Conv2dParams(prev, co, 1, bias=False))
+            layers.append(GroupNormParams(g, co))
+            if not last:
+                layers.append(_Marker("relu"))
+            if drop > 0 and not last:
+                layers.append(_Marker("dropout2d", drop))
+            prev = co
+        self.layers = nn.ModuleList(layers)   # indices match the reference's nn.Sequential
+
+    def set_input_dropout_rate(self, rate: float) -> None:
+        self.input_dropout.p = rate
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        hw = x.shape[1] * x.shape[2]
+        x = channel_dropout(x, self.input_dropout.p, self.training, hw)
+        i = 0
+        mods = list(self.layers)
+        while i < len(mods):
+            conv, norm = mods[i], mods[i + 1]
+            i += 2
+            relu = i < len(mods) and isinstance(mods[i], _Marker) and mods[i].kind == "relu"
+            x = norm(conv(x), relu=relu)
+            if relu:
+                i += 1
+            if i < len(mods) and isinstance(mods[i], _Marker) and mods[i].kind == "dropout2d":
+                x = channel_dropout(x, mods[i].p, self.training, hw)
+                i += 1
+        return x
+
+
+class EdgeAwareSmoothingConv2D(nn.Module):
+    """Directional filter bank + residual edge gate (spatial.py:278-339) on NHWC tensors."""
+
+    def __init__(self, channels: int, num_layers: int = 2, kernel_size: int = 3, padding: int = 1, gate_hidden: int = 64,
+                 gate_kernel_size: int = 3, num_directions: int = 4, coarse_dilation: int = 3, rank: int = 4):
+        super().__init__()
+        if num_directions != 4 or kernel_size != 3 or gate_kernel_size != 3:
+            raise NotImplementedError("HIP stencil supports num_directions=4, 3x3 bank and 3x3 gate convolutions")
+        self.channels, self.num_directions, self.coarse_dilation = channels, num_directions, coarse_dilation
+        self.K, self.rank = num_directions * 2, rank
+        t = [[[0., 0., 0.], [1 / 3, 1 / 3, 1 / 3], [0., 0., 0.]], [[0., 1 / 3, 0.], [0., 1 / 3, 0.], [0., 1 / 3, 0.]],
+             [[1 / 3, 0., 0.], [0., 1 / 3, 0.], [0., 0., 1 / 3]], [[0., 0., 1 / 3], [0., 1 / 3, 0.], [1 / 3, 0., 0.]]]
+        bank = torch.tensor(t).unsqueeze(1).unsqueeze(1).expand(4, channels, 1, 3, 3).contiguous()
+        self.register_buffer("bank", bank)                                  # kept for state-dict parity; fixed in-kernel
+        sx = torch.tensor([[-1., 0., 1.], [-2., 0., 2.], [-1., 0., 1.]]) / 4.0
+        sy = torch.tensor([[-1., -2., -1.], [0., 0., 0.], [1., 2., 1.]]) / 4.0
+        self.register_buffer("sobel_x", sx.reshape(1, 1, 3, 3).expand(channels, 1, 3, 3).contiguous())
+        self.register_buffer("sobel_y", sy.reshape(1, 1, 3, 3).expand(channels, 1, 3, 3).contiguous())
+        self.mix_backbone = nn.ModuleList([Conv2dParams(2 * channels, gate_hidden, 3), _Marker("relu")])
+        self.mix_head_A = Conv2dParams(gate_hidden, self.K * rank, 1)
+        self.mix_head_B = Conv2dParams(gate_hidden, channels * rank, 1)
+        self.gate_net = nn.ModuleList([Conv2dParams(channels, gate_hidden, 3), _Marker("relu"),
+                                       Conv2dParams(gate_hidden, channels, 3), _Marker("sigmoid")])
+        self.min_gate: float = 0.0
+
+    def set_min_gate(self, value: float) -> None:
+        self.min_gate = float(value)
+
+    def forward(self, x: torch.Tensor, return_gate: bool = False):
+        g = Fh.SobelFn.apply(x)                                   # [B,H,W,2C] = cat[dx, dy]
+        feat = self.mix_backbone[0](g, ACT_RELU)
+        a_logit = self.mix_head_A(feat)
+        b_logit = self.mix_head_B(feat)
+        smoothed, residual = Fh.EdgeSmoothFn.apply(x, a_logit, b_logit, self.rank, self.coarse_dilation)
+        g1 = self.gate_net[0](residual, ACT_RELU)
+        gate_raw = self.gate_net[2](g1, ACT_SIGMOID)
+        out, gate = Fh.GateBlendFn.apply(smoothed, residual, gate_raw, self.min_gate)
+        return (out, gate) if return_gate else out
+
+
+class GatedResidualBlock(nn.Module):
+    """dropout -> conv1d(k=3, dil) -> GroupNorm -> gate(1x1) ; y = g * relu(n) + (1-g) * res  (tcn.py:78-111), fused."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, dilation: int = 1, dropout_rate: float = 0.0,
+                 num_groups: int = 8, projection_channels: Optional[int] = None):
+        super().__init__()
+        if kernel_size != 3:
+            raise NotImplementedError("fused TCN block implements kernel_size=3")
+        if projection_channels not in (None, out_channels):
+            raise NotImplementedError("projection_channels != out_channels is not on the hot path")
+        self.in_channels, self.out_channels, self.dilation = in_channels, out_channels, dilation
+        self.dropout = _Marker("dropout1d", dropout_rate)
+        self.conv = Conv1dParams(in_channels, out_channels, 3)
+        self.norm = GroupNormParams(num_groups, out_channels)
+        self.gate = Conv1dParams(out_channels, out_channels, 1)
+        self.needs_projection = in_channels != out_channels
+        self.projection = Conv1dParams(in_channels, out_channels, 1) if self.needs_projection else _Marker("identity")
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x [B,T,HW..,Cin] -> [B,T,HW..,Cout]."""
+        channel_dropout(x, self.dropout.p, self.training, 1)
+        pw = self.projection.weight if self.needs_projection else None
+        pb = self.projection.bias if self.needs_projection else None
+        return Fh.TcnBlockFn.apply(x, self.conv.weight, self.conv.bias, self.norm.weight, self.norm.bias, self.gate.weight,
+                                   self.gate.bias, pw, pb, self.dilation, self.norm.num_groups, self.norm.eps)
+
+
+class TCNEncoder(nn.Module):
+    """Stack of GatedResidualBlocks, pooling='none' (tcn.py:114-302) on [B,T,HW..,C] tensors."""
+
+    def __init__(self, in_channels: int, channels: Sequence[int], kernel_size: int = 3, dilations: Optional[Sequence[int]] = None,
+                 dropout_rate: float = 0.0, num_groups: int = 8, pooling: str = "none"):
+        super().__init__()
+        if pooling != "none":
+            raise NotImplementedError("only pooling='none' is used by RepresentationModel (representation.py:165)")
+        channels = list(channels)
+        dilations = [1] * len(channels) if dilations is None else list(dilations)
+        assert len(dilations) == len(channels)
+        self.in_channels, self.out_channels, self.pooling = in_channels, channels[-1], pooling
+        layers, prev = [], in_channels
+        for co, d in zip(channels, dilations):
+            layers.append(GatedResidualBlock(prev, co, kernel_size, d, dropout_rate, num_groups))
+            prev = co
+        self.layers = nn.ModuleList(layers)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+
+class FiLMLayer(nn.Module):
+    """gamma/beta = two independent conv1x1 -> ReLU -> conv1x1 nets (conditioning.py:55-80)."""
+
+    def __init__(self, cond_dim: int, target_dim: int, hidden_dim: Optional[int] = None):
+        super().__init__()
+        hidden_dim = max(cond_dim, target_dim) // 2 if hidden_dim is None else hidden_dim
+        self.cond_dim, self.target_dim = cond_dim, target_dim
+        self.gamma_network = nn.ModuleList([Conv2dParams(cond_dim, hidden_dim, 1), _Marker("relu"), Conv2dParams(hidden_dim, target_dim, 1)])
+        self.beta_network = nn.ModuleList([Conv2dParams(cond_dim, hidden_dim, 1), _Marker("relu"), Conv2dParams(hidden_dim, target_dim, 1)])
+        with torch.no_grad():
+            self.gamma_network[2].weight.normal_(0.0, 0.01)
+            self.gamma_network[2].bias.fill_(1.0)
+            self.beta_network[2].weight.normal_(0.0, 0.01)
+            self.beta_network[2].bias.zero_()
+
+    def forward(self, cond: torch.Tensor):
+        g = self.gamma_network[2](self.gamma_network[0](cond, ACT_RELU))
+        b = self.beta_network[2](self.beta_network[0](cond, ACT_RELU))
+        return g, b
+
+
+class Conv2DHead(nn.Module):
+    """conv1x1 -> ReLU -> ... -> conv1x1 decoder (heads.py:128-198, kernel 1, activation 'none')."""
+
+    def __init__(self, in_channels: int, channels: Sequence[int], out_channels: int):
+        super().__init__()
+        layers, prev = [], in_channels
+        for ch in channels:
+            layers += [Conv2dParams(prev, ch, 1), _Marker("relu")]
+            prev = ch
+        layers.append(Conv2dParams(prev, out_channels, 1))
+        self.layers = nn.ModuleList(layers)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        mods = list(self.layers)
+        for i in range(0, len(mods) - 1, 2):
+            x = mods[i](x, ACT_RELU)
+        return mods[-1](x)

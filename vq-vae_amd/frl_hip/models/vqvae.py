@@ -1,0 +1,123 @@
+"""VQ-VAE over (time, y, x, feature) tiles: RepresentationModel encoder -> vector quantizer -> 1x1-conv decoders.
+
+The reference tree no longer ships a quantizer or decoder; this module implements the build
+definition of SURVEY.md section 8a rows a11/a12 behind the surviving legacy trainer contract
+(scripts/train_vqvae.py:183-198,221-224,287):
+  * `model.quant.codebook` is an nn.Parameter [K, emb_dim] whose qualified name contains "quant.codebook";
+  * `model.quant.codebook_size`, `model.quant.emb_dim`, `model.attach_codebook_manager(m)`;
+  * `model(batch) -> (cont_pred, cat_logits, canopy_pred, vq_loss, perplexity)`.
+The class extends RepresentationModel so the encoder keeps the reference's state-dict keys (reference checkpoints load
+with strict=False) and the extra keys are `quant.codebook`, `decoder_type.layers.{0,2}.*`, `decoder_phase.layers.{0,2}.*`.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import functional as Fh
+from .. import ops
+from .blocks import Conv2DHead
+from .representation import RepresentationModel
+
+
+class VectorQuantizer(nn.Module):
+    """argmin-L2 codebook lookup with straight-through estimator; 'st' (gradient) or 'ema' codebook updates."""
+
+    def __init__(self, codebook_size: int = 256, emb_dim: int = 64, beta: float = 0.25, quantizer: str = "st",
+                 ema_decay: float = 0.99, ema_eps: float = 1e-5):
+        super().__init__()
+        if quantizer not in ("st", "ema"):
+            raise ValueError("quantizer must be 'st' or 'ema' (scripts/train_vqvae.py:412)")
+        self.codebook_size, self.emb_dim, self.beta = codebook_size, emb_dim, beta
+        self.quantizer, self.ema_decay, self.ema_eps = quantizer, ema_decay, ema_eps
+        self.codebook = nn.Parameter(torch.empty(codebook_size, emb_dim).uniform_(-1.0 / codebook_size, 1.0 / codebook_size),
+                                     requires_grad=(quantizer == "st"))
+        if quantizer == "ema":
+            self.register_buffer("ema_count", torch.zeros(codebook_size))
+            self.register_buffer("ema_sum", self.codebook.detach().clone())
+        self.last_counts: Optional[torch.Tensor] = None
+
+    def forward(self, z_rows: torch.Tensor):
+        """z_rows [N, d] -> (z_q [N,d] with straight-through gradient, vq_loss, perplexity, idx int32 [N])."""
+        zq, l_cb, l_cm, perp, idx, counts = Fh.VQFn.apply(z_rows, self.codebook)
+        self.last_counts = counts
+        if self.quantizer == "ema":
+            vq_loss = self.beta * l_cm
+            if self.training:
+                with torch.no_grad():
+                    _, _, sums = ops.vq_bwd(None, z_rows.detach(), self.codebook.detach(), idx, counts, None, 0.0,
+                                            want_gz=False, want_ge=False, want_sums=True)
+                    ops.vq_ema_update(sums, counts, self.ema_count, self.ema_sum, self.codebook.data, self.ema_decay, self.ema_eps)
+        else:
+            vq_loss = l_cb + self.beta * l_cm
+        return zq, vq_loss, perp, idx
+
+
+class VQVAE(RepresentationModel):
+    """Encoder -> VQ(z_type) -> type decoder ; phase path conditioned on stopgrad(z_type_cont) -> phase decoder."""
+
+    def __init__(self, in_features: int = 64, codebook_size: int = 256, emb_dim: int = 64, beta: float = 0.25,
+                 hidden: int = 128, quantizer: str = "st", ema_decay: float = 0.99, ema_eps: float = 1e-5,
+                 phase: bool = True, phase_codebook_size: int = 0, lambda_recon: float = 1.0, lambda_vq: float = 1.0,
+                 **repr_kwargs):
+        repr_kwargs.setdefault("z_type_dim", emb_dim)
+        if repr_kwargs["z_type_dim"] != emb_dim:
+            raise ValueError("emb_dim must equal z_type_dim (the quantizer acts on z_type)")
+        if "type_encoder_channels" not in repr_kwargs and emb_dim != 64:
+            repr_kwargs["type_encoder_channels"] = (128, emb_dim)
+        super().__init__(type_in_channels=in_features, phase_in_channels=in_features, **repr_kwargs)
+        self.in_features, self.phase, self.lambda_recon, self.lambda_vq = in_features, phase, lambda_recon, lambda_vq
+        self.quant = VectorQuantizer(codebook_size, emb_dim, beta, quantizer, ema_decay, ema_eps)
+        self.decoder_type = Conv2DHead(emb_dim, [hidden], in_features)
+        if phase:
+            self.decoder_phase = Conv2DHead(self.z_phase_dim, [hidden], in_features)
+            if phase_codebook_size:
+                self.quant_phase = VectorQuantizer(phase_codebook_size, self.z_phase_dim, beta, quantizer, ema_decay, ema_eps)
+        self.codebook_manager = None
+
+    def attach_codebook_manager(self, manager) -> None:
+        """scripts/train_vqvae.py:197-198: the manager tracks usage / dead codes from `quant.last_counts`."""
+        self.codebook_manager = manager
+
+    def forward_tiles(self, tile: torch.Tensor, mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """tile [B,T,H,W,F] (any float dtype, GPU) -> dict(loss, l_type, l_phase, vq_loss, perplexity, idx, ...)."""
+        self._require_gpu(tile)
+        tile = self._rows(tile)
+        b, t, hh, ww, f = tile.shape
+        with torch.no_grad():
+            x_type = ops.mean_time(tile)                                   # [B,H,W,F]
+        z_type, gate = self.forward_nhwc(x_type, return_gate=True)          # [B,H,W,d]
+        d = z_type.shape[-1]
+        zq, vq_loss, perp, idx = self.quant(z_type.reshape(-1, d))
+        xhat_type = self.decoder_type(zq.reshape(b, hh, ww, d))
+        l_type = Fh.mse_loss(xhat_type, x_type, mask)
+        out = dict(z_type=z_type, gate=gate, idx=idx, vq_loss=vq_loss, perplexity=perp, xhat_type=xhat_type, l_type=l_type)
+        loss = self.lambda_recon * l_type + self.lambda_vq * vq_loss
+        if self.phase:
+            z_phase = self.forward_phase_nhwc(tile, z_type.detach())       # [B,T,H,W,zp]
+            zp_in = z_phase
+            if hasattr(self, "quant_phase"):
+                zpq, pvq, pperp, pidx = self.quant_phase(z_phase.reshape(-1, z_phase.shape[-1]))
+                zp_in = zpq.reshape(z_phase.shape)
+                loss = loss + self.lambda_vq * pvq
+                out.update(idx_phase=pidx, vq_loss_phase=pvq, perplexity_phase=pperp)
+            xhat_phase = self.decoder_phase(zp_in)
+            pmask = None if mask is None else mask.unsqueeze(1).expand(b, t, hh, ww).contiguous()
+            l_phase = Fh.mse_loss(xhat_phase, tile, pmask)
+            loss = loss + self.lambda_recon * l_phase
+            out.update(z_phase=z_phase, xhat_phase=xhat_phase, l_phase=l_phase)
+        out["loss"] = loss
+        if self.codebook_manager is not None and hasattr(self.codebook_manager, "update"):
+            self.codebook_manager.update(self.quant.last_counts)
+        return out
+
+    def forward(self, batch, return_gate: bool = False):
+        """Legacy contract (scripts/train_vqvae.py:287): dict batch -> (cont_pred, cat_logits, canopy_pred, vq_loss, perplexity).
+
+        A tensor argument keeps the RepresentationModel.forward semantics ([B,C,H,W] -> z_type)."""
+        if isinstance(batch, dict):
+            out = self.forward_tiles(batch["tile"], batch.get("mask"))
+            return out["xhat_type"], {}, out.get("xhat_phase"), out["vq_loss"], out["perplexity"]
+        return super().forward(batch, return_gate)

@@ -15,6 +15,39 @@ from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, F32, check  # noqa: F40
 
 _WS = {}
 
+# ----------------------------------------------------------------------------------------------
+# optional per-op HIP-event timing (bench.py roofline): events are recorded on the stream the kernels are launched on
+# ----------------------------------------------------------------------------------------------
+_TIMING = {"on": False, "events": {}}
+
+
+def set_timing(on: bool) -> None:
+    _TIMING["on"] = bool(on)
+    _TIMING["events"] = {}
+
+
+def timing_summary():
+    """name -> (calls, total_ms); synchronises the device."""
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in _TIMING["events"].items()}
+
+
+def _timed(name):
+    def deco(fn):
+        def wrapper(*a, **kw):
+            if not _TIMING["on"]:
+                return fn(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            _TIMING["events"].setdefault(name, []).append((e0, e1))
+            return out
+        wrapper.__name__ = fn.__name__
+        wrapper.__doc__ = fn.__doc__
+        return wrapper
+    return deco
+
 
 def _dt(t: torch.Tensor) -> int:
     if t.dtype == torch.float32:
@@ -60,6 +93,7 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 # pointwise convolution (reference: nn.Conv2d(.,.,1) call sites, see csrc/pw_conv.hip)
 # ----------------------------------------------------------------------------------------------
+@_timed("conv1x1_fwd")
 def conv1x1_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE) -> torch.Tensor:
     cout, cin = w.shape[0], w.shape[1]
     _chk_rows(x, cin, "conv1x1_fwd.x")
@@ -71,6 +105,7 @@ def conv1x1_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], 
     return y
 
 
+@_timed("conv1x1_bwd_data")
 def conv1x1_bwd_data(dy: torch.Tensor, w: torch.Tensor, y: Optional[torch.Tensor] = None, act: int = ACT_NONE) -> torch.Tensor:
     cout, cin = w.shape[0], w.shape[1]
     _chk_rows(dy, cout, "conv1x1_bwd_data.dy")
@@ -82,6 +117,7 @@ def conv1x1_bwd_data(dy: torch.Tensor, w: torch.Tensor, y: Optional[torch.Tensor
     return dx
 
 
+@_timed("conv1x1_bwd_weight")
 def conv1x1_bwd_weight(dy: torch.Tensor, x: torch.Tensor, y: Optional[torch.Tensor] = None, act: int = ACT_NONE,
                        want_bias: bool = True, scalar_frags: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     cout, cin = dy.shape[-1], x.shape[-1]
@@ -102,6 +138,7 @@ def conv1x1_bwd_weight(dy: torch.Tensor, x: torch.Tensor, y: Optional[torch.Tens
 # ----------------------------------------------------------------------------------------------
 # vector quantizer (csrc/vq.hip)
 # ----------------------------------------------------------------------------------------------
+@_timed("vq_assign")
 def vq_assign(z: torch.Tensor, codebook: torch.Tensor):
     """z [N,d] rows, codebook [K,d] f32 -> (idx int32 [N], z_q [N,d], stats f32 [4], counts int32 [K])."""
     k, d = codebook.shape
@@ -119,6 +156,7 @@ def vq_assign(z: torch.Tensor, codebook: torch.Tensor):
     return idx, zq, stats, counts
 
 
+@_timed("vq_bwd")
 def vq_bwd(g_out: Optional[torch.Tensor], z: torch.Tensor, codebook: torch.Tensor, idx: torch.Tensor,
            counts: torch.Tensor, gscale: Optional[torch.Tensor], beta: float, want_gz: bool = True,
            want_ge: bool = True, want_sums: bool = False):
@@ -143,6 +181,7 @@ def vq_ema_update(sums, counts, ema_count, ema_sum, codebook, decay: float, eps:
 # ----------------------------------------------------------------------------------------------
 # GroupNorm over NHWC rows (csrc/norm.hip)
 # ----------------------------------------------------------------------------------------------
+@_timed("groupnorm_fwd")
 def groupnorm_fwd(x: torch.Tensor, gamma, beta, groups: int, eps: float = 1e-5, relu: bool = False):
     """x [B, ..., C] -> (y, mean [B,G], rstd [B,G])."""
     b, c = x.shape[0], x.shape[-1]
@@ -156,6 +195,7 @@ def groupnorm_fwd(x: torch.Tensor, gamma, beta, groups: int, eps: float = 1e-5, 
     return y, mean, rstd
 
 
+@_timed("groupnorm_bwd")
 def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, groups: int, relu: bool = False):
     b, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (b * c)
@@ -172,6 +212,7 @@ def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, groups: int, relu: bool = Fals
 # ----------------------------------------------------------------------------------------------
 # streaming elementwise ops (csrc/elementwise.hip)
 # ----------------------------------------------------------------------------------------------
+@_timed("mse_fwd")
 def mse_fwd(pred: torch.Tensor, target: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Returns stats f32 [2] = {mean squared error over valid elements, number of valid elements}."""
     c = pred.shape[-1]
@@ -185,6 +226,7 @@ def mse_fwd(pred: torch.Tensor, target: torch.Tensor, mask: Optional[torch.Tenso
     return out
 
 
+@_timed("mse_bwd")
 def mse_bwd(pred, target, mask, gscale: Optional[torch.Tensor], stats) -> torch.Tensor:
     c = pred.shape[-1]
     d = torch.empty_like(pred)
@@ -193,6 +235,7 @@ def mse_bwd(pred, target, mask, gscale: Optional[torch.Tensor], stats) -> torch.
     return d
 
 
+@_timed("film_modulate_fwd")
 def film_modulate_fwd(h: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
     """h [B,T,HW..,C], gamma/beta [B,HW..,C]."""
     b, t, c = h.shape[0], h.shape[1], h.shape[-1]
@@ -203,6 +246,7 @@ def film_modulate_fwd(h: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) 
     return out
 
 
+@_timed("film_modulate_bwd")
 def film_modulate_bwd(dout, h, gamma):
     b, t, c = h.shape[0], h.shape[1], h.shape[-1]
     hw = h.numel() // (b * t * c)
@@ -214,6 +258,7 @@ def film_modulate_bwd(dout, h, gamma):
     return dh, dg, db
 
 
+@_timed("gate_blend_fwd")
 def gate_blend_fwd(smoothed, residual, gate_raw, min_gate: float):
     out = torch.empty_like(smoothed)
     gate = torch.empty_like(smoothed)
@@ -222,6 +267,7 @@ def gate_blend_fwd(smoothed, residual, gate_raw, min_gate: float):
     return out, gate
 
 
+@_timed("gate_blend_bwd")
 def gate_blend_bwd(dout, dgate_ext, residual, gate_raw, min_gate: float):
     dres = torch.empty_like(dout)
     dgraw = torch.empty_like(dout)
@@ -230,6 +276,7 @@ def gate_blend_bwd(dout, dgate_ext, residual, gate_raw, min_gate: float):
     return dres, dgraw
 
 
+@_timed("mean_time")
 def mean_time(tile: torch.Tensor) -> torch.Tensor:
     """tile [B,T,H,W,C] -> [B,H,W,C]."""
     b, t = tile.shape[0], tile.shape[1]
@@ -238,15 +285,18 @@ def mean_time(tile: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+@_timed("add")
+def add(a: torch.Tensor, b: torch.Tensor, scale_b: float = 1.0) -> torch.Tensor:
+    """out = a + scale_b * b"""
     out = torch.empty_like(a)
-    check(_lib.load().frl_add(_p(a), _p(b), _p(out), a.numel(), _dt(a), _stream()), "frl_add")
+    check(_lib.load().frl_add(_p(a), _p(b), float(scale_b), _p(out), a.numel(), _dt(a), _stream()), "frl_add")
     return out
 
 
 # ----------------------------------------------------------------------------------------------
 # 3x3 convolution (csrc/conv3x3.hip); x [B,H,W,Cin], w [Cout,Cin,3,3]
 # ----------------------------------------------------------------------------------------------
+@_timed("conv3x3_fwd")
 def conv3x3_fwd(x, w, bias, act: int = ACT_NONE):
     b, h, wd, cin = x.shape
     cout = w.shape[0]
@@ -257,6 +307,7 @@ def conv3x3_fwd(x, w, bias, act: int = ACT_NONE):
     return y
 
 
+@_timed("conv3x3_bwd_data")
 def conv3x3_bwd_data(dy, w, y=None, act: int = ACT_NONE):
     b, h, wd, cout = dy.shape
     cin = w.shape[1]
@@ -266,6 +317,7 @@ def conv3x3_bwd_data(dy, w, y=None, act: int = ACT_NONE):
     return dx
 
 
+@_timed("conv3x3_bwd_weight")
 def conv3x3_bwd_weight(dy, x, y=None, act: int = ACT_NONE, scalar_frags: bool = False):
     b, h, wd, cout = dy.shape
     cin = x.shape[-1]
@@ -281,6 +333,7 @@ def conv3x3_bwd_weight(dy, x, y=None, act: int = ACT_NONE, scalar_frags: bool = 
 # ----------------------------------------------------------------------------------------------
 # fixed stencils of EdgeAwareSmoothingConv2D (csrc/stencil.hip)
 # ----------------------------------------------------------------------------------------------
+@_timed("sobel_fwd")
 def sobel_fwd(x):
     b, h, w, c = x.shape
     g = torch.empty(b, h, w, 2 * c, dtype=x.dtype, device=x.device)
@@ -288,6 +341,7 @@ def sobel_fwd(x):
     return g
 
 
+@_timed("sobel_bwd")
 def sobel_bwd(dg):
     b, h, w, c2 = dg.shape
     dx = torch.empty(b, h, w, c2 // 2, dtype=dg.dtype, device=dg.device)
@@ -295,6 +349,7 @@ def sobel_bwd(dg):
     return dx
 
 
+@_timed("edge_smooth_fwd")
 def edge_smooth_fwd(x, a_logit, b_logit, rank: int, coarse_dilation: int):
     b, h, w, c = x.shape
     sm, res = torch.empty_like(x), torch.empty_like(x)
@@ -305,6 +360,7 @@ def edge_smooth_fwd(x, a_logit, b_logit, rank: int, coarse_dilation: int):
     return sm, res, a_soft, b_soft
 
 
+@_timed("edge_smooth_bwd")
 def edge_smooth_bwd(d_smoothed, x, a_soft, b_soft, rank: int, coarse_dilation: int):
     b, h, w, c = x.shape
     dx = torch.empty_like(x)
@@ -318,6 +374,7 @@ def edge_smooth_bwd(d_smoothed, x, a_soft, b_soft, rank: int, coarse_dilation: i
 # ----------------------------------------------------------------------------------------------
 # fused TCN block (csrc/tcn_fwd.hip, tcn_bwd.hip); x [B,T,HW..,Cin]
 # ----------------------------------------------------------------------------------------------
+@_timed("tcn_block_fwd")
 def tcn_block_fwd(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, dilation: int, groups: int,
                   eps: float = 1e-5):
     b, t, cin = x.shape[0], x.shape[1], x.shape[-1]
@@ -331,6 +388,7 @@ def tcn_block_fwd(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b,
     return y
 
 
+@_timed("tcn_block_bwd")
 def tcn_block_bwd(x, dy, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, dilation: int, groups: int,
                   eps: float = 1e-5):
     """Returns dict(dx, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b[, proj_w, proj_b]) gradients."""

@@ -1,0 +1,73 @@
+"""Train-step skeleton of the reference (frl/training/representation/step.py:121-125,1057-1090; loops.py:97-110):
+zero_grad -> forward -> total loss -> isfinite guard -> backward -> clip_grad_norm_(1.0) -> AdamW.step -> per-batch LR step.
+
+Optimizer wiring follows the legacy VQ-VAE trainer (scripts/train_vqvae.py:221-253): two AdamW groups (codebook without
+weight decay), betas (0.9, 0.95), cosine LR from lr to min_lr.  With torch.distributed initialised the gradients are
+all-reduced by `parallel.BucketedGradAllReduce` (RCCL on GPUs, gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from ..parallel import BucketedGradAllReduce
+from .schedules import beta_schedule, cosine_lr
+
+
+class VQVAETrainer:
+    def __init__(self, model, lr: float = 1e-4, min_lr: float = 1e-6, weight_decay: float = 0.01, max_norm: float = 1.0,
+                 total_steps: int = 1000, betas=(0.9, 0.95), check_finite: bool = True, fused_optimizer: bool = True,
+                 beta_schedule_cfg: Optional[dict] = None):
+        self.model = model
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        cb = [p for n, p in named if "quant" in n and "codebook" in n]
+        rest = [p for n, p in named if not ("quant" in n and "codebook" in n)]
+        groups = [{"params": rest, "weight_decay": weight_decay}]
+        if cb:
+            groups.append({"params": cb, "weight_decay": 0.0})
+        on_gpu = bool(rest) and rest[0].is_cuda
+        self.opt = torch.optim.AdamW(groups, lr=lr, betas=betas, fused=(fused_optimizer and on_gpu))
+        self.params = [p for _, p in named]
+        self.lr, self.min_lr, self.total_steps, self.max_norm = lr, min_lr, total_steps, max_norm
+        self.check_finite = check_finite
+        self.beta_schedule_cfg = beta_schedule_cfg
+        self.step_idx = 0
+        self.epoch = 0
+        self.skipped = 0
+        self.reducer = BucketedGradAllReduce(named) if (dist.is_available() and dist.is_initialized()) else None
+
+    def set_epoch(self, epoch: int):
+        """Per-epoch curricula: beta schedule of configs/vae_v0.yaml:21-27."""
+        self.epoch = epoch
+        if self.beta_schedule_cfg is not None and hasattr(self.model, "quant"):
+            self.model.quant.beta = beta_schedule(epoch, self.beta_schedule_cfg)
+
+    def _all_finite(self, loss: torch.Tensor) -> bool:
+        ok = torch.isfinite(loss.detach()).float()
+        if self.reducer is not None:            # every rank must take the same branch or the collectives deadlock
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        return bool(ok.item() > 0)
+
+    def step(self, tile: torch.Tensor, mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        lr_now = cosine_lr(self.step_idx, self.total_steps, self.lr, self.min_lr)
+        for g in self.opt.param_groups:
+            g["lr"] = lr_now
+        self.model.train()
+        self.opt.zero_grad(set_to_none=True)
+        out = self.model.forward_tiles(tile, mask)
+        loss = out["loss"]
+        if self.check_finite and not self._all_finite(loss):
+            self.skipped += 1                     # step.py:1057-1074: skip the batch, keep training
+            if self.reducer is not None:
+                self.reducer.reset()
+            return out
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        out["grad_norm"] = torch.nn.utils.clip_grad_norm_(self.params, self.max_norm)
+        self.opt.step()
+        self.step_idx += 1
+        out["lr"] = lr_now
+        return out
