@@ -37,10 +37,13 @@ int frl_device_arch(char* buf, int n); /* must report gfx950 */
 /* ---- pointwise (1x1) convolution --------------------------------------------------------------------------------
  * nn.Conv2d(.,.,1): frl/models/conv2d_encoder.py:106-114; spatial.py:262-263; representation.py:169;
  * conditioning.py:55-67; decoder template heads.py:128-198.  w [Cout][Cin], bias [Cout] or NULL. */
+/* every forward / bwd_data convolution entry point takes a workspace of frl_conv_workspace_bytes(Cin, Cout, taps) bytes
+ * (taps = 1 pointwise, 3 temporal, 9 spatial; 6 covers a whole TCN block) for the packed MFMA weight image it builds. */
+size_t frl_conv_workspace_bytes(int Cin, int Cout, int taps);
 int frl_conv1x1_fwd(const void* x, const float* w, const float* bias, void* y, int64_t P, int Cin, int Cout, int act,
-                    int dtype, frl_stream_t stream);
+                    int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
 int frl_conv1x1_bwd_data(const void* dy, const void* y, int act, const float* w, void* dx, int64_t P, int Cin, int Cout,
-                         int dtype, frl_stream_t stream);
+                         int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
 size_t frl_conv1x1_bwd_weight_workspace_bytes(int64_t P, int Cin, int Cout);
 int frl_conv1x1_bwd_weight(const void* dy, const void* y, int act, const void* x, float* dw, float* dbias, int64_t P,
                            int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
@@ -55,9 +58,9 @@ int frl_conv_tap_bwd_weight(const void* dy, const void* y, int act, const void* 
  * nn.Conv2d(.,.,3,padding=1): frl/models/spatial.py:258-261 (mix_backbone), :266-272 (gate_net).
  * x [B][H][W][Cin], w [Cout][Cin][3][3]. */
 int frl_conv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
-                    int act, int dtype, frl_stream_t stream);
+                    int act, int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
 int frl_conv3x3_bwd_data(const void* dy, const void* y, int act, const float* w, void* dx, int B, int H, int W, int Cin,
-                         int Cout, int dtype, frl_stream_t stream);
+                         int Cout, int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
 size_t frl_conv3x3_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int frl_conv3x3_bwd_weight(const void* dy, const void* y, int act, const void* x, float* dw, float* dbias, int B, int H,
                            int W, int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, int flags, frl_stream_t stream);
@@ -95,8 +98,8 @@ int frl_gate_blend_bwd(const void* dout, const void* dgate_ext, const void* resi
  * proj_w [Cout][Cin] or NULL (identity residual, tcn.py:71-76). */
 int frl_tcn_block_fwd(const void* x, const float* conv_w, const float* conv_b, const float* gn_w, const float* gn_b,
                       const float* gate_w, const float* gate_b, const float* proj_w, const float* proj_b, void* y,
-                      int64_t npix, int HW, int T, int Cin, int Cout, int dilation, int G, float eps, int dtype,
-                      frl_stream_t stream);
+                      int64_t npix, int HW, int T, int Cin, int Cout, int dilation, int G, float eps, int dtype, void* ws,
+                      size_t ws_bytes, frl_stream_t stream);
 size_t frl_tcn_block_bwd_workspace_bytes(int64_t npix, int Cout);
 int frl_tcn_block_bwd(const void* x, const void* dy, const float* conv_w, const float* conv_b, const float* gn_w,
                       const float* gn_b, const float* gate_w, const float* gate_b, const float* proj_w,
@@ -104,7 +107,8 @@ int frl_tcn_block_bwd(const void* x, const void* dy, const float* conv_w, const 
                       int64_t npix, int HW, int T, int Cin, int Cout, int dilation, int G, float eps, int dtype, void* ws,
                       size_t ws_bytes, frl_stream_t stream);
 int frl_tcn_block_bwd_data(const void* dconv, const void* dres, const float* conv_w, const float* proj_w, void* dx,
-                           int64_t npix, int HW, int T, int Cin, int Cout, int dilation, int dtype, frl_stream_t stream);
+                           int64_t npix, int HW, int T, int Cin, int Cout, int dilation, int dtype, void* ws, size_t ws_bytes,
+                           frl_stream_t stream);
 
 /* ---- FiLM modulation, time mean, add ---------------------------------------------------------------------------
  * z = gamma * h + beta broadcast over T (frl/models/representation.py:369-372); h [B][T][HW][C], gamma [B][HW][C]. */

@@ -11,6 +11,7 @@
 // Roofline: MFMA (147 456 FLOP/px at 128->64 vs 384 B/px bf16 = 384 FLOP/B, above the 312 FLOP/B balance point).
 #include "frl_common.hpp"
 #include "frl_host.hpp"
+#include "frl_reduce.hpp"
 
 #define C3_TH 8
 #define C3_TW 16
@@ -64,9 +65,43 @@ __device__ __forceinline__ void stage_halo(T* __restrict__ halo, int pitch, cons
 // ------------------------------------------------------------------------------------------------
 // forward / bwd_data
 // ------------------------------------------------------------------------------------------------
+// Packed weight image: block (oc0/4, ck/CK) holds [9 taps][4 m][NF][64] fragments; written once per call.
+template <typename T, int NF>
+__global__ void c3_pack_kernel(typename DT<T>::frag_t* __restrict__ dst, const float* __restrict__ Wt, int64_t w_so, int64_t w_si,
+                               int tap_rev, int Cin, int Cout) {
+  constexpr int FE = DT<T>::FE;
+  constexpr int q = NF * FE, CK = 4 * q;
+  const int MB = (Cout + 15) >> 4, qo = 4 * MB;
+  const int nck = (Cin + CK - 1) / CK, noc = (MB + 3) / 4;
+  const int per_block = 9 * 4 * NF * 64;
+  const int total = noc * nck * per_block;
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
+    const int blk = g / per_block, i = g % per_block;
+    const int oc0 = (blk / nck) * 4, ck = (blk % nck) * CK;
+    const int ln = i & 63, fs = i >> 6;
+    const int s = fs % NF, m = (fs / NF) & 3, tap = fs / (NF * 4);
+    const int r = ln & 15, kq = ln >> 4;
+    const int oc = qo * (r >> 2) + 4 * (oc0 + m) + (r & 3);
+    const int tsrc = tap_rev ? 8 - tap : tap;
+    const bool mok = (oc0 + m) < MB;
+    if constexpr (FE == 8) {
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ic = ck + q * kq + 8 * s + e;
+        v[e] = (mok && oc < Cout && ic < Cin) ? (bf16)Wt[oc * w_so + ic * w_si + tsrc] : (bf16)0.f;
+      }
+      dst[g] = v;
+    } else {
+      const int ic = ck + q * kq + s;
+      dst[g] = (mok && oc < Cout && ic < Cin) ? Wt[oc * w_so + ic * w_si + tsrc] : 0.f;
+    }
+  }
+}
+
 template <typename T, int NF>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const T* __restrict__ X, const T* __restrict__ Xmask, int mask_act,
-                                                      const float* __restrict__ Wt, int64_t w_so, int64_t w_si, int tap_rev,
+                                                      const typename DT<T>::frag_t* __restrict__ Wpk,
                                                       const float* __restrict__ bias, T* __restrict__ Y, int B, int H, int W,
                                                       int Cin, int Cout, int act) {
   typedef typename DT<T>::frag_t frag_t;
@@ -94,26 +129,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const T* __restrict__ X, c
     for (int ck = 0; ck < Cin; ck += CK) {
       __syncthreads();
       stage_halo<T>(halo, pitch, X, Xmask, mask_act, b, y0, x0, H, W, Cin, ck, CK, tid);
-      // weights of this (out-chunk, in-chunk): wl[((tap*4 + m)*NF + s)*64 + lane]
-      for (int i = tid; i < 9 * 4 * NF * 64; i += 256) {
-        const int ln = i & 63, fs = i >> 6;
-        const int s = fs % NF, m = (fs / NF) & 3, tap = fs / (NF * 4);
-        const int r = ln & 15, kq = ln >> 4;
-        const int oc = qo * (r >> 2) + 4 * (oc0 + m) + (r & 3);
-        const int tsrc = tap_rev ? 8 - tap : tap;
-        if constexpr (FE == 8) {
-          bf16x8 v;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int ic = ck + q * kq + 8 * s + e;
-            v[e] = (m < nmb && oc < Cout && ic < Cin) ? (bf16)Wt[oc * w_so + ic * w_si + tsrc] : (bf16)0.f;
-          }
-          wl[i] = v;
-        } else {
-          const int ic = ck + q * kq + s;
-          wl[i] = (m < nmb && oc < Cout && ic < Cin) ? Wt[oc * w_so + ic * w_si + tsrc] : 0.f;
-        }
-      }
+      // weights of this (out-chunk, in-chunk): wl[((tap*4 + m)*NF + s)*64 + lane], copied from the packed image
+      copy_frags_lds<T>(wl, Wpk + (size_t)((oc0 / 4) * ((Cin + CK - 1) / CK) + ck / CK) * (9 * 4 * NF * 64), 9 * 4 * NF * 64, tid, 256);
       __syncthreads();
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
@@ -313,49 +330,52 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict_
   if (tid < OCT) my[(int64_t)OCT * Cin * 9 + tid] = bsum;
 }
 
-// out[oc][j] = sum_wg slab[wg][ocl][j]; rows beyond Cout are dropped
-__global__ void conv3x3_slab_reduce_kernel(const float* __restrict__ slab, int nslab, int OCT, int Cin9, int oc_base, int Cout,
-                                           float* __restrict__ dW, float* __restrict__ dB) {
-  const int64_t n = (int64_t)OCT * Cin9 + OCT;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < nslab; ++k) s += slab[(int64_t)k * n + i];
-  if (i < (int64_t)OCT * Cin9) {
-    const int ocl = (int)(i / Cin9);
-    if (oc_base + ocl < Cout) dW[(int64_t)(oc_base + ocl) * Cin9 + (i % Cin9)] = s;
-  } else if (dB != nullptr) {
-    const int ocl = (int)(i - (int64_t)OCT * Cin9);
-    if (oc_base + ocl < Cout) dB[oc_base + ocl] = s;
+// epilogue of the slab reduction: out[oc][j] = sum_wg slab[wg][ocl][j]; rows beyond Cout are dropped
+struct C3Epi {
+  int OCT, Cin9, oc_base, Cout; float* dW; float* dB;
+  __device__ void operator()(int64_t i, float s) const {
+    if (i < (int64_t)OCT * Cin9) {
+      const int ocl = (int)(i / Cin9);
+      if (oc_base + ocl < Cout) dW[(int64_t)(oc_base + ocl) * Cin9 + (i % Cin9)] = s;
+    } else if (dB != nullptr) {
+      const int ocl = (int)(i - (int64_t)OCT * Cin9);
+      if (oc_base + ocl < Cout) dB[oc_base + ocl] = s;
+    }
   }
-}
+};
 
 // ------------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NF>
 static int launch_c3(const void* x, const void* xm, int mask_act, const float* w, int64_t so, int64_t si, int tap_rev,
-                     const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act, hipStream_t st) {
+                     const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act, void* ws, size_t ws_bytes,
+                     hipStream_t st) {
   typedef typename DT<T>::frag_t frag_t;
   constexpr int CK = 4 * NF * DT<T>::FE;
+  const int MBt = (Cout + 15) / 16;
+  const size_t nfrag = (size_t)((MBt + 3) / 4) * ((Cin + CK - 1) / CK) * 9 * 4 * NF * 64;
+  if (ws == nullptr || ws_bytes < nfrag * sizeof(frag_t)) return frl_fail(-4, "conv3x3: workspace too small for the packed weights");
+  FRL_LAUNCH((c3_pack_kernel<T, NF>), dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, (frag_t*)ws, w, so, si, tap_rev, Cin, Cout);
   const size_t lds = (size_t)C3_HP * C3_WP * (CK + C3<T>::PADE) * sizeof(T) + (size_t)9 * 4 * NF * 64 * sizeof(frag_t);
   auto kern = conv3x3_kernel<T, NF>;
   FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int tiles = B * ((H + C3_TH - 1) / C3_TH) * ((W + C3_TW - 1) / C3_TW);
-  FRL_LAUNCH(kern, dim3(tiles), dim3(256), lds, st, (const T*)x, (const T*)xm, mask_act, w, so, si, tap_rev, bias, (T*)y, B,
+  FRL_LAUNCH(kern, dim3(tiles), dim3(256), lds, st, (const T*)x, (const T*)xm, mask_act, (const frag_t*)ws, bias, (T*)y, B,
                      H, W, Cin, Cout, act);
   return frl_check_launch("conv3x3");
 }
 
 static int c3_dispatch(const void* x, const void* xm, int mask_act, const float* w, int64_t so, int64_t si, int tap_rev,
-                       const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act, int dtype, hipStream_t st) {
+                       const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act, int dtype, void* ws, size_t ws_bytes,
+                       hipStream_t st) {
   if (B <= 0 || H <= 0 || W <= 0) return frl_fail(-2, "conv3x3: empty input");
   if (dtype == FRL_F32) {
-    if (Cin <= 16) return launch_c3<float, 4>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, st);
-    return launch_c3<float, 8>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, st);
+    if (Cin <= 16) return launch_c3<float, 4>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st);
+    return launch_c3<float, 8>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st);
   } else if (dtype == FRL_BF16) {
-    if (Cin <= 32) return launch_c3<bf16, 1>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, st);
-    return launch_c3<bf16, 2>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, st);
+    if (Cin <= 32) return launch_c3<bf16, 1>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st);
+    return launch_c3<bf16, 2>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st);
   }
   return frl_fail(-2, "conv3x3: bad dtype");
 }
@@ -369,15 +389,15 @@ extern "C" {
 
 // x [B][H][W][Cin], w [Cout][Cin][3][3] f32, bias [Cout] f32 or null, y [B][H][W][Cout]
 int frl_conv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
-                    int dtype, hipStream_t stream) {
-  return c3_dispatch(x, nullptr, 0, w, (int64_t)Cin * 9, 9, 0, bias, y, B, H, W, Cin, Cout, act, dtype, stream);
+                    int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+  return c3_dispatch(x, nullptr, 0, w, (int64_t)Cin * 9, 9, 0, bias, y, B, H, W, Cin, Cout, act, dtype, ws, ws_bytes, stream);
 }
 
 // dx = conv3x3(dy .* act'(y), w^T flipped)
 int frl_conv3x3_bwd_data(const void* dy, const void* y, int act, const float* w, void* dx, int B, int H, int W, int Cin, int Cout,
-                         int dtype, hipStream_t stream) {
+                         int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
   return c3_dispatch(dy, act != FRL_ACT_NONE ? y : nullptr, act, w, 9, (int64_t)Cin * 9, 1, nullptr, dx, B, H, W, Cout, Cin,
-                     FRL_ACT_NONE, dtype, stream);
+                     FRL_ACT_NONE, dtype, ws, ws_bytes, stream);
 }
 
 size_t frl_conv3x3_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
@@ -407,8 +427,7 @@ int frl_conv3x3_bwd_weight(const void* dy, const void* y, int act, const void* x
       FRL_LAUNCH(kern, dim3(nwg), dim3(256), lds, stream, (const bf16*)dy, (const bf16*)ym, act, (const bf16*)x, (float*)ws, B,
                          H, W, Cin, Cout, oc_base, tpw, (flags & 1) ? 0 : 1);
     } else return frl_fail(-2, "conv3x3_bwd_weight: bad dtype");
-    FRL_LAUNCH(conv3x3_slab_reduce_kernel, dim3((unsigned)((slab_n + 255) / 256)), dim3(256), 0, stream, (const float*)ws, nwg, 64,
-                       Cin * 9, oc_base, Cout, dw, dbias);
+    launch_slab_reduce<float, C3Epi>((const float*)ws, nwg, slab_n, C3Epi{64, Cin * 9, oc_base, Cout, dw, dbias}, stream);
   }
   return frl_check_launch("conv3x3_bwd_weight");
 }

@@ -42,12 +42,20 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(const T* __restrict__ 
   }
 }
 
-__global__ void mse_finalize_kernel(const double* __restrict__ partial, int n, float* __restrict__ out /*{mean, n_valid}*/) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void mse_finalize_kernel(const double* __restrict__ partial, int n, float* __restrict__ out /*{mean, n_valid}*/) {
+  __shared__ double rs[256], rc[256];
   double s = 0.0, c = 0.0;
-  for (int i = 0; i < n; ++i) { s += partial[2 * i]; c += partial[2 * i + 1]; }
-  out[0] = c > 0.0 ? (float)(s / c) : 0.f;
-  out[1] = (float)c;
+  for (int i = threadIdx.x; i < n; i += 256) { s += partial[2 * i]; c += partial[2 * i + 1]; }
+  rs[threadIdx.x] = s; rc[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { rs[threadIdx.x] += rs[threadIdx.x + o]; rc[threadIdx.x] += rc[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = rc[0] > 0.0 ? (float)(rs[0] / rc[0]) : 0.f;
+    out[1] = (float)rc[0];
+  }
 }
 
 template <typename T, int V>
@@ -214,7 +222,7 @@ int frl_mse_fwd(const void* pred, const void* target, const uint8_t* mask, int64
     grid = ew_grid(P * C); FRL_LAUNCH((mse_partial_kernel<float, 1>), dim3(grid), dim3(256), 0, stream, (const float*)pred, (const float*)target, mask, P, C, partial),
     grid = ew_grid(P * (C / 8)); FRL_LAUNCH((mse_partial_kernel<bf16, 8>), dim3(grid), dim3(256), 0, stream, (const bf16*)pred, (const bf16*)target, mask, P, C, partial),
     grid = ew_grid(P * C); FRL_LAUNCH((mse_partial_kernel<bf16, 1>), dim3(grid), dim3(256), 0, stream, (const bf16*)pred, (const bf16*)target, mask, P, C, partial))
-  FRL_LAUNCH(mse_finalize_kernel, dim3(1), dim3(64), 0, stream, (const double*)partial, (int)grid, out);
+  FRL_LAUNCH(mse_finalize_kernel, dim3(1), dim3(256), 0, stream, (const double*)partial, (int)grid, out);
   return frl_check_launch("mse_fwd");
 }
 

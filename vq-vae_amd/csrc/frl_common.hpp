@@ -215,3 +215,27 @@ __device__ __forceinline__ void pack_weights_lds(typename DT<T>::frag_t* __restr
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Pre-packed weights: a tiny prologue kernel writes the fragment-ordered image once per call into the caller's
+// workspace (global memory, L2 resident); every workgroup then fills its LDS copy with 16-byte coalesced loads
+// instead of re-gathering the f32 master weights element by element.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NF>
+__global__ void pack_weights_kernel(typename DT<T>::frag_t* __restrict__ dst, const float* __restrict__ W, int Cout, int Cin, int MB,
+                                    int64_t so, int64_t si) {
+  pack_weights_lds<T, NF>(dst, W, Cout, Cin, MB, so, si, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
+}
+
+// copies `nfrag` fragments (a multiple of 64) global -> LDS with 16-byte accesses
+template <typename T>
+__device__ __forceinline__ void copy_frags_lds(typename DT<T>::frag_t* __restrict__ dst, const typename DT<T>::frag_t* __restrict__ src,
+                                               int nfrag, int tid, int nthreads) {
+  if constexpr (DT<T>::FE == 8) {
+    for (int i = tid; i < nfrag; i += nthreads) dst[i] = src[i];
+  } else {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+    f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+    for (int i = tid; i < nfrag / 4; i += nthreads) d4[i] = s4[i];
+  }
+}

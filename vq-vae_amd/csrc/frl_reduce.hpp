@@ -1,0 +1,39 @@
+// Fixed-order parallel reduction of per-workgroup slabs:  v[i] = sum_k slab[k * n + i],  epi(i, v[i]).
+// 256 threads = 32 columns x 8 slab groups; each thread walks its group's slabs 4 at a time (independent loads in
+// flight), the 8 groups are combined through LDS in a fixed order, so results are bit-reproducible run to run.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "frl_host.hpp"
+
+template <typename V, class Epi>
+__global__ __launch_bounds__(256) void slab_reduce_t(const V* __restrict__ slab, int nslab, int64_t n, Epi epi) {
+  __shared__ V red[8][33];
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + col;
+  V s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  if (i < n) {
+    int k = grp;
+    for (; k + 24 < nslab; k += 32) {
+      s0 += slab[(int64_t)k * n + i];
+      s1 += slab[(int64_t)(k + 8) * n + i];
+      s2 += slab[(int64_t)(k + 16) * n + i];
+      s3 += slab[(int64_t)(k + 24) * n + i];
+    }
+    for (; k < nslab; k += 8) s0 += slab[(int64_t)k * n + i];
+  }
+  red[grp][col] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && i < n) {
+    V s = red[0][col];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) s += red[g][col];
+    epi(i, s);
+  }
+}
+
+template <typename V, class Epi>
+static inline void launch_slab_reduce(const V* slab, int nslab, int64_t n, Epi epi, hipStream_t st) {
+  const unsigned grid = (unsigned)((n + 31) / 32);
+  FRL_LAUNCH((slab_reduce_t<V, Epi>), dim3(grid), dim3(256), 0, st, slab, nslab, n, epi);
+}

@@ -5,6 +5,7 @@
 // All reductions are fixed-order (no float atomics) so results are bit-reproducible.
 #include "frl_common.hpp"
 #include "frl_host.hpp"
+#include "frl_reduce.hpp"
 
 // One workgroup per sample.  Thread layout: vpr = C / V channel-vectors per row, rpi = 256 / vpr rows per
 // iteration; each thread owns a fixed channel vector and strides over rows.  MODE 0: sums of x and x^2;
@@ -152,14 +153,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
-// out[c] = sum_b in[b][c]  (fixed order)
-__global__ void colsum_rows_kernel(const float* __restrict__ in, int B, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int b = 0; b < B; ++b) s += in[(int64_t)b * C + c];
-  out[c] = s;
-}
+struct StoreEpi {
+  float* out;
+  __device__ void operator()(int64_t i, float s) const { out[i] = s; }
+};
 
 template <typename T, int V>
 static int gn_fwd_impl(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int B,
@@ -194,8 +191,8 @@ static int gn_bwd_impl(const void* dy, const void* x, const float* gamma, const 
   if (grid > 4096) grid = 4096;
   FRL_LAUNCH((gn_bwd_apply_kernel<T, V>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)x, (const T*)dy, gamma,
                      beta, mean, rstd, (const float*)grp, (T*)dx, tv, HW, C, G, relu);
-  FRL_LAUNCH(colsum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)sdy, B, C, dbeta);
-  FRL_LAUNCH(colsum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)sdyx, B, C, dgamma);
+  launch_slab_reduce<float, StoreEpi>((const float*)sdy, B, C, StoreEpi{dbeta}, st);
+  launch_slab_reduce<float, StoreEpi>((const float*)sdyx, B, C, StoreEpi{dgamma}, st);
   return frl_check_launch("groupnorm_bwd");
 }
 

@@ -12,9 +12,8 @@
 
 template <typename T, int NF, int NT>
 __global__ __launch_bounds__(256) void pw_conv_kernel(
-    const T* __restrict__ X, const T* __restrict__ Xmask, int mask_act, const float* __restrict__ W,
-    int64_t w_so, int64_t w_si, const float* __restrict__ bias, T* __restrict__ Y, int64_t P, int Cin,
-    int Cout, int act) {
+    const T* __restrict__ X, const T* __restrict__ Xmask, int mask_act, const typename DT<T>::frag_t* __restrict__ Wpk,
+    const float* __restrict__ bias, T* __restrict__ Y, int64_t P, int Cin, int Cout, int act) {
   typedef typename DT<T>::frag_t frag_t;
   constexpr int FE = DT<T>::FE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -22,7 +21,7 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(
   const int MB = (Cout + 15) >> 4;
   const int qo = 4 * MB;
   constexpr int q = NF * FE;
-  pack_weights_lds<T, NF>(wl, W, Cout, Cin, MB, w_so, w_si, threadIdx.x, 256);
+  copy_frags_lds<T>(wl, Wpk, MB * NF * 64, threadIdx.x, 256);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -105,54 +104,63 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(
 
 template <typename T, int NF>
 static int launch_pw(const void* x, const void* xmask, int mask_act, const float* w, int64_t so, int64_t si,
-                     const float* bias, void* y, int64_t P, int Cin, int Cout, int act, hipStream_t st) {
+                     const float* bias, void* y, int64_t P, int Cin, int Cout, int act, void* ws, size_t ws_bytes, hipStream_t st) {
+  typedef typename DT<T>::frag_t frag_t;
   constexpr int NT = 2;
   const int MB = (Cout + 15) / 16;
-  const size_t lds = (size_t)MB * NF * 64 * sizeof(typename DT<T>::frag_t);
+  const size_t lds = (size_t)MB * NF * 64 * sizeof(frag_t);
   if (lds > 160 * 1024) return frl_fail(-3, "pw_conv: weights exceed LDS (Cin*Cout too large)");
+  if (ws == nullptr || ws_bytes < lds) return frl_fail(-4, "pw_conv: workspace too small for the packed weights");
+  FRL_LAUNCH((pack_weights_kernel<T, NF>), dim3((MB * NF * 64 + 255) / 256), dim3(256), 0, st, (frag_t*)ws, w, Cout, Cin, MB, so, si);
   auto kern = pw_conv_kernel<T, NF, NT>;
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t ngroups = ((P + 15) / 16 + NT - 1) / NT;
   int64_t grid = (ngroups + 3) / 4;
   if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
-  FRL_LAUNCH(kern, dim3((unsigned)grid), dim3(256), lds, st, (const T*)x, (const T*)xmask, mask_act, w,
-                     so, si, bias, (T*)y, P, Cin, Cout, act);
+  FRL_LAUNCH(kern, dim3((unsigned)grid), dim3(256), lds, st, (const T*)x, (const T*)xmask, mask_act,
+             (const frag_t*)ws, bias, (T*)y, P, Cin, Cout, act);
   return frl_check_launch("pw_conv");
 }
 
 // Dispatch over padded input width.  f32: Cp in {16,32,64,128,256} -> NF = Cp/4; bf16: Cp in {32..256} -> NF = Cp/32.
 int frl_pw_dispatch(const void* x, const void* xmask, int mask_act, const float* w, int64_t so, int64_t si,
-                    const float* bias, void* y, int64_t P, int Cin, int Cout, int act, int dtype, hipStream_t st) {
+                    const float* bias, void* y, int64_t P, int Cin, int Cout, int act, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
   if (P <= 0) return 0;
   if (Cin < 1 || Cout < 1 || Cin > 256 || Cout > 1024) return frl_fail(-2, "pw_conv: unsupported channel count");
   if (dtype == FRL_F32) {
-    if (Cin <= 16) return launch_pw<float, 4>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, st);
-    if (Cin <= 32) return launch_pw<float, 8>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, st);
-    if (Cin <= 64) return launch_pw<float, 16>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, st);
-    if (Cin <= 128) return launch_pw<float, 32>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, st);
-    return launch_pw<float, 64>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, st);
+    if (Cin <= 16) return launch_pw<float, 4>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
+    if (Cin <= 32) return launch_pw<float, 8>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
+    if (Cin <= 64) return launch_pw<float, 16>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
+    if (Cin <= 128) return launch_pw<float, 32>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
+    return launch_pw<float, 64>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
   } else if (dtype == FRL_BF16) {
-    if (Cin <= 32) return launch_pw<bf16, 1>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, st);
-    if (Cin <= 64) return launch_pw<bf16, 2>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, st);
-    if (Cin <= 128) return launch_pw<bf16, 4>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, st);
-    return launch_pw<bf16, 8>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, st);
+    if (Cin <= 32) return launch_pw<bf16, 1>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
+    if (Cin <= 64) return launch_pw<bf16, 2>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
+    if (Cin <= 128) return launch_pw<bf16, 4>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
+    return launch_pw<bf16, 8>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
   }
   return frl_fail(-2, "pw_conv: bad dtype");
 }
 
 extern "C" {
 
+// workspace for the packed-weight image of any pointwise / 3-tap / 3x3 convolution of this library
+size_t frl_conv_workspace_bytes(int Cin, int Cout, int taps) {
+  const size_t ci = (size_t)(Cin + 31) / 32 * 32, co = (size_t)(Cout + 15) / 16 * 16;
+  return (size_t)taps * ci * co * sizeof(float) + 4096;
+}
+
 int frl_conv1x1_fwd(const void* x, const float* w, const float* bias, void* y, int64_t P, int Cin, int Cout,
-                    int act, int dtype, hipStream_t stream) {
-  return frl_pw_dispatch(x, nullptr, 0, w, Cin, 1, bias, y, P, Cin, Cout, act, dtype, stream);
+                    int act, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+  return frl_pw_dispatch(x, nullptr, 0, w, Cin, 1, bias, y, P, Cin, Cout, act, dtype, ws, ws_bytes, stream);
 }
 
 // dx[P][Cin] = (dy .* act'(y))[P][Cout] * W[Cout][Cin];  y may be null (act none)
 int frl_conv1x1_bwd_data(const void* dy, const void* y, int act, const float* w, void* dx, int64_t P, int Cin,
-                         int Cout, int dtype, hipStream_t stream) {
+                         int Cout, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
   return frl_pw_dispatch(dy, act != FRL_ACT_NONE ? y : nullptr, act, w, 1, Cin, nullptr, dx, P, Cout, Cin,
-                         FRL_ACT_NONE, dtype, stream);
+                         FRL_ACT_NONE, dtype, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -9,6 +9,7 @@
 // tcn.py:56-69 (3 temporal taps = 3 shifted calls), conditioning.py:55-67, representation.py:169, decoders.
 #include "frl_common.hpp"
 #include "frl_host.hpp"
+#include "frl_reduce.hpp"
 
 #define WG_KP 64
 
@@ -176,27 +177,24 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(
   if (tid < Cout) my[(int64_t)Cout * Cin + tid] = bsum;
 }
 
-// out[i] (+)= sum over slabs, fixed order.  dw strides let the caller scatter a tap slice of a
+// Epilogue of the fixed-order slab reduction (frl_reduce.hpp).  dw strides let the caller scatter a tap slice of a
 // [Cout][Cin][ntap] tensor: dst = dW[oc * dso + ic * dsi].
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nslab, int Cout, int Cin, float* dW,
-                                   int64_t dso, int64_t dsi, float* dB, int accumulate_bias) {
-  const int64_t n = (int64_t)Cout * Cin + Cout;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < nslab; ++k) s += slab[(int64_t)k * n + i];
-  if (i < (int64_t)Cout * Cin) {
-    const int oc = (int)(i / Cin), ic = (int)(i % Cin);
-    dW[oc * dso + ic * dsi] = s;
-  } else if (dB != nullptr) {
-    const int oc = (int)(i - (int64_t)Cout * Cin);
-    if (accumulate_bias) dB[oc] += s; else dB[oc] = s;
+struct WgradEpi {
+  float* dW; int64_t dso, dsi; float* dB; int Cout, Cin, accumulate_bias;
+  __device__ void operator()(int64_t i, float s) const {
+    if (i < (int64_t)Cout * Cin) {
+      const int oc = (int)(i / Cin), ic = (int)(i % Cin);
+      dW[oc * dso + ic * dsi] = s;
+    } else if (dB != nullptr) {
+      const int oc = (int)(i - (int64_t)Cout * Cin);
+      if (accumulate_bias) dB[oc] += s; else dB[oc] = s;
+    }
   }
-}
+};
 
 static int wgrad_nwg(int64_t P) {
   int64_t n = (P + WG_KP - 1) / WG_KP;
-  if (n > 512) n = 512;
+  if (n > 256) n = 256;
   if (n < 1) n = 1;
   return (int)n;
 }
@@ -266,8 +264,7 @@ int frl_conv_tap_bwd_weight(const void* dy, const void* y, int act, const void* 
   else return frl_fail(-2, "bwd_weight: bad dtype");
   if (rc) return rc;
   const int64_t n = (int64_t)Cout * Cin + Cout;
-  FRL_LAUNCH(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)ws,
-                     wgrad_nwg(P), Cout, Cin, dw, dso, dsi, dbias, (flags & 2) ? 1 : 0);
+  launch_slab_reduce<float, WgradEpi>((const float*)ws, wgrad_nwg(P), n, WgradEpi{dw, dso, dsi, dbias, Cout, Cin, (flags & 2) ? 1 : 0}, stream);
   return frl_check_launch("slab_reduce");
 }
 

@@ -7,12 +7,14 @@
 // dx itself is produced by frl_tcn_block_bwd_data (conv^T over dconv + residual path).
 #include "tcn_common.hpp"
 #include "frl_host.hpp"
+#include "frl_reduce.hpp"
 
 template <typename T, int NFI, int MBO>
-__global__ __launch_bounds__(256) void tcn_block_bwd_kernel(const T* __restrict__ X, const T* __restrict__ DY, const float* __restrict__ Wc,
+__global__ __launch_bounds__(256) void tcn_block_bwd_kernel(const T* __restrict__ X, const T* __restrict__ DY,
+                                                            const typename DT<T>::frag_t* __restrict__ Wpk,
                                                             const float* __restrict__ bc, const float* __restrict__ gn_w,
-                                                            const float* __restrict__ gn_b, const float* __restrict__ Wg,
-                                                            const float* __restrict__ bg, const float* __restrict__ Wp,
+                                                            const float* __restrict__ gn_b,
+                                                            const float* __restrict__ bg, int has_proj,
                                                             const float* __restrict__ bp, T* DCONV, T* __restrict__ DGPRE,
                                                             T* __restrict__ NORMED, T* __restrict__ DRES, float* __restrict__ slab, TcnArgs a) {
   typedef typename DT<T>::frag_t frag_t;
@@ -26,12 +28,9 @@ __global__ __launch_bounds__(256) void tcn_block_bwd_kernel(const T* __restrict_
   frag_t* wl_proj = wl_gateT + MBO * NFO * 64;                      // [MBO][NFI][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, kc = lane >> 4;
-  for (int k = 0; k < 3; ++k)
-    pack_weights_lds<T, NFI>(wl_conv + k * MBO * NFI * 64, Wc + k, a.Cout, a.Cin, MBO, (int64_t)a.Cin * 3, 3, tid, 256);
-  pack_weights_lds<T, NFO>(wl_gate, Wg, a.Cout, a.Cout, MBO, a.Cout, 1, tid, 256);
-  pack_weights_lds<T, NFO>(wl_gateT, Wg, a.Cout, a.Cout, MBO, 1, a.Cout, tid, 256);
-  if (Wp != nullptr) pack_weights_lds<T, NFI>(wl_proj, Wp, a.Cout, a.Cin, MBO, a.Cin, 1, tid, 256);
+  copy_frags_lds<T>(wl_conv, Wpk, (3 * MBO * NFI + 2 * MBO * NFO + (has_proj ? MBO * NFI : 0)) * 64, tid, 256);
   __syncthreads();
+  const float* Wp = has_proj ? bp : nullptr;   // non-null marker for the projection branches below
 
   const bool fast_in = (a.Cin == 4 * NFI * FE), fast_out = (a.Cout == 4 * Q);
   const int cg = a.Cout / a.G;
@@ -187,19 +186,15 @@ __global__ __launch_bounds__(256) void tcn_block_bwd_kernel(const T* __restrict_
 
 static unsigned tcn_bwd_grid(int64_t npix) {
   int64_t g = ((npix + 15) / 16 + 3) / 4;
-  if (g > 1024) g = 1024;
+  if (g > 512) g = 512;
   if (g < 1) g = 1;
   return (unsigned)g;
 }
 
-// out[i] = sum_k slab[k][i]
-__global__ void tcn_slab_reduce_kernel(const float* __restrict__ slab, int nslab, int n, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * n) return;
-  float s = 0.f;
-  for (int k = 0; k < nslab; ++k) s += slab[(int64_t)k * 2 * n + i];
-  if (i < n) dgamma[i] = s; else dbeta[i - n] = s;
-}
+struct TcnGbEpi {
+  int n; float* dgamma; float* dbeta;
+  __device__ void operator()(int64_t i, float s) const { if (i < n) dgamma[i] = s; else dbeta[i - n] = s; }
+};
 
 template <typename T, int NFI, int MBO>
 static int launch_tcn_bwd(const void* x, const void* dy, const float* wc, const float* bc, const float* gw, const float* gb, const float* wg,
@@ -214,9 +209,12 @@ static int launch_tcn_bwd(const void* x, const void* dy, const float* wc, const 
   auto kern = tcn_block_bwd_kernel<T, NFI, MBO>;
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned grid = tcn_bwd_grid(a.npix);
-  FRL_LAUNCH(kern, dim3(grid), dim3(256), lds, st, (const T*)x, (const T*)dy, wc, bc, gw, gb, wg, bg, wp, bp, (T*)dconv, (T*)dgpre,
-                     (T*)normed, (T*)dres, ws, a);
-  FRL_LAUNCH(tcn_slab_reduce_kernel, dim3((2 * a.Cout + 255) / 256), dim3(256), 0, st, (const float*)ws, (int)grid, a.Cout, dgamma, dbeta);
+  frag_t* pk = reinterpret_cast<frag_t*>(reinterpret_cast<char*>(ws) + (((size_t)grid * 2 * a.Cout * sizeof(float) + 255) / 256) * 256);
+  FRL_LAUNCH((tcn_pack_kernel<T, NFI, MBO, NFI>), dim3(32), dim3(256), 0, st, pk, 1, wc, (int64_t)a.Cin * 3, (int64_t)3, 0, wg, wp,
+             (int64_t)a.Cin, (int64_t)1, a.Cin, a.Cin, a.Cout);
+  FRL_LAUNCH(kern, dim3(grid), dim3(256), lds, st, (const T*)x, (const T*)dy, (const frag_t*)pk, bc, gw, gb, bg, wp ? 1 : 0, bp, (T*)dconv,
+             (T*)dgpre, (T*)normed, (T*)dres, ws, a);
+  launch_slab_reduce<float, TcnGbEpi>((const float*)ws, (int)grid, 2 * a.Cout, TcnGbEpi{a.Cout, dgamma, dbeta}, st);
   return frl_check_launch("tcn_block_bwd");
 }
 
@@ -242,7 +240,9 @@ int frl_tcn_check(int Cin, int Cout, int G, int dtype);
 
 extern "C" {
 
-size_t frl_tcn_block_bwd_workspace_bytes(int64_t npix, int Cout) { return (size_t)tcn_bwd_grid(npix) * 2 * Cout * sizeof(float); }
+size_t frl_tcn_block_bwd_workspace_bytes(int64_t npix, int Cout) {
+  return (size_t)tcn_bwd_grid(npix) * 2 * Cout * sizeof(float) + 256 + (size_t)6 * 128 * 128 * sizeof(float);   // slabs + packed weights
+}
 
 // Side outputs (all [B][T][HW][Cout], dtype): dconv, dgpre, normed, dres; dgamma/dbeta [Cout] f32.
 int frl_tcn_block_bwd(const void* x, const void* dy, const float* conv_w, const float* conv_b, const float* gn_w, const float* gn_b,

@@ -141,3 +141,23 @@ __device__ __forceinline__ void tcn_stats(float (&mean)[4 * MBO], float (&rstd)[
     rstd[j] = 1.f / sqrtf(var + a.eps);
   }
 }
+
+// One launch writes every packed weight image a TCN kernel needs (conv taps, gate, gate^T, projection) to the workspace.
+// mode 0: forward (conv, gate, proj) ; mode 1: backward (conv, gate, gate^T, proj) ; mode 2: tconv3 (conv [rev], extra pointwise)
+template <typename T, int NFI, int MBO, int NFP>
+__global__ void tcn_pack_kernel(typename DT<T>::frag_t* __restrict__ dst, int mode, const float* __restrict__ Wc, int64_t so, int64_t si,
+                                int rev, const float* __restrict__ Wg, const float* __restrict__ Wp, int64_t pso, int64_t psi, int Cp,
+                                int Cin, int Cout) {
+  constexpr int NFO = 4 * MBO / DT<T>::FE;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+  for (int k = 0; k < 3; ++k)
+    pack_weights_lds<T, NFI>(dst + k * MBO * NFI * 64, Wc + (rev ? 2 - k : k), Cout, Cin, MBO, so, si, tid, nt);
+  typename DT<T>::frag_t* p = dst + 3 * MBO * NFI * 64;
+  if (mode != 2) {
+    pack_weights_lds<T, NFO>(p, Wg, Cout, Cout, MBO, Cout, 1, tid, nt);
+    p += MBO * NFO * 64;
+    if (mode == 1) { pack_weights_lds<T, NFO>(p, Wg, Cout, Cout, MBO, 1, Cout, tid, nt); p += MBO * NFO * 64; }
+  }
+  if (Wp != nullptr) pack_weights_lds<T, NFP>(p, Wp, Cout, Cp, MBO, pso, psi, tid, nt);
+}
+

@@ -8,10 +8,10 @@
 #include "frl_host.hpp"
 
 template <typename T, int NFI, int MBO>
-__global__ __launch_bounds__(256) void tcn_block_fwd_kernel(const T* __restrict__ X, const float* __restrict__ Wc, const float* __restrict__ bc,
+__global__ __launch_bounds__(256) void tcn_block_fwd_kernel(const T* __restrict__ X, const typename DT<T>::frag_t* __restrict__ Wpk,
+                                                            const float* __restrict__ bc,
                                                             const float* __restrict__ gn_w, const float* __restrict__ gn_b,
-                                                            const float* __restrict__ Wg, const float* __restrict__ bg,
-                                                            const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                            const float* __restrict__ bg, int has_proj, const float* __restrict__ bp,
                                                             T* __restrict__ Y, TcnArgs a) {
   typedef typename DT<T>::frag_t frag_t;
   constexpr int FE = DT<T>::FE;
@@ -23,11 +23,9 @@ __global__ __launch_bounds__(256) void tcn_block_fwd_kernel(const T* __restrict_
   frag_t* wl_proj = wl_gate + MBO * NFO * 64;                       // [MBO][NFI][64] (only if Wp)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, kc = lane >> 4;
-  for (int k = 0; k < 3; ++k)
-    pack_weights_lds<T, NFI>(wl_conv + k * MBO * NFI * 64, Wc + k, a.Cout, a.Cin, MBO, (int64_t)a.Cin * 3, 3, tid, 256);
-  pack_weights_lds<T, NFO>(wl_gate, Wg, a.Cout, a.Cout, MBO, a.Cout, 1, tid, 256);
-  if (Wp != nullptr) pack_weights_lds<T, NFI>(wl_proj, Wp, a.Cout, a.Cin, MBO, a.Cin, 1, tid, 256);
+  copy_frags_lds<T>(wl_conv, Wpk, (3 * MBO * NFI + MBO * NFO + (has_proj ? MBO * NFI : 0)) * 64, tid, 256);
   __syncthreads();
+  const float* Wp = has_proj ? bp : nullptr;   // non-null marker for the projection branches below
 
   const bool fast_in = (a.Cin == 4 * NFI * FE), fast_out = (a.Cout == 4 * Q);
   const int64_t ntile = (a.npix + 15) >> 4;
@@ -105,9 +103,9 @@ __global__ __launch_bounds__(256) void tcn_block_fwd_kernel(const T* __restrict_
 //   Y[t] = sum_k W_k X[t + (k-1) dil]  (+ R[t] if add_r)  (+ Wp R2[t])
 // Weff_k[o][i] = W[o * so + i * si + (rev ? 2 - k : k)]; used as conv^T in the TCN backward.
 template <typename T, int NFI, int MBO, int NFP>
-__global__ __launch_bounds__(256) void tconv3_kernel(const T* __restrict__ X, const float* __restrict__ W, int64_t so, int64_t si, int rev,
-                                                     const T* __restrict__ R, const T* __restrict__ R2, const float* __restrict__ Wp,
-                                                     int64_t pso, int64_t psi, int Cp, T* __restrict__ Y, TcnArgs a) {
+__global__ __launch_bounds__(256) void tconv3_kernel(const T* __restrict__ X, const typename DT<T>::frag_t* __restrict__ Wpk,
+                                                     const T* __restrict__ R, const T* __restrict__ R2, int has_p,
+                                                     int Cp, T* __restrict__ Y, TcnArgs a) {
   typedef typename DT<T>::frag_t frag_t;
   constexpr int FE = DT<T>::FE;
   constexpr int Q = 4 * MBO, NFO = Q / FE;
@@ -116,10 +114,9 @@ __global__ __launch_bounds__(256) void tconv3_kernel(const T* __restrict__ X, co
   frag_t* wl_p = wl_conv + 3 * MBO * NFI * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, kc = lane >> 4;
-  for (int k = 0; k < 3; ++k)
-    pack_weights_lds<T, NFI>(wl_conv + k * MBO * NFI * 64, W + (rev ? 2 - k : k), a.Cout, a.Cin, MBO, so, si, tid, 256);
-  if (Wp != nullptr) pack_weights_lds<T, NFP>(wl_p, Wp, a.Cout, Cp, MBO, pso, psi, tid, 256);
+  copy_frags_lds<T>(wl_conv, Wpk, (3 * MBO * NFI + (has_p ? MBO * NFP : 0)) * 64, tid, 256);
   __syncthreads();
+  const bool Wp = has_p != 0;
   const bool fast_in = (a.Cin == 4 * NFI * FE), fast_out = (a.Cout == 4 * Q), fast_p = (Cp == 4 * NFP * FE);
   const int64_t ntile = (a.npix + 15) >> 4;
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
@@ -133,7 +130,7 @@ __global__ __launch_bounds__(256) void tconv3_kernel(const T* __restrict__ X, co
 #pragma unroll
       for (int m = 0; m < MBO; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
       tconv_at<T, NFI, MBO>(acc, X, row0, a, t, a.Cin, kc, fast_in, wl_conv, lane);
-      if (Wp != nullptr) {
+      if (Wp) {
         LQTile<T, NFP> rt;
         lq_load<T, NFP>(rt, R2, row0 + (int64_t)t * a.HW, Cp, kc, fast_p);
         pw_at<T, NFP, MBO>(acc, rt, wl_p, lane);
@@ -165,27 +162,35 @@ static unsigned tcn_grid(int64_t npix) {
 
 template <typename T, int NFI, int MBO>
 static int launch_tcn_fwd(const void* x, const float* wc, const float* bc, const float* gw, const float* gb, const float* wg,
-                          const float* bg, const float* wp, const float* bp, void* y, const TcnArgs& a, hipStream_t st) {
+                          const float* bg, const float* wp, const float* bp, void* y, const TcnArgs& a, void* ws, size_t ws_bytes,
+                          hipStream_t st) {
   typedef typename DT<T>::frag_t frag_t;
   constexpr int NFO = 4 * MBO / DT<T>::FE;
   const size_t lds = (size_t)(3 * MBO * NFI + MBO * NFO + (wp ? MBO * NFI : 0)) * 64 * sizeof(frag_t);
   if (lds > 160 * 1024) return frl_fail(-3, "tcn_block_fwd: weights exceed LDS");
+  if (ws == nullptr || ws_bytes < lds) return frl_fail(-4, "tcn_block_fwd: workspace too small for the packed weights");
+  FRL_LAUNCH((tcn_pack_kernel<T, NFI, MBO, NFI>), dim3(32), dim3(256), 0, st, (frag_t*)ws, 0, wc, (int64_t)a.Cin * 3, (int64_t)3, 0, wg, wp,
+             (int64_t)a.Cin, (int64_t)1, a.Cin, a.Cin, a.Cout);
   auto kern = tcn_block_fwd_kernel<T, NFI, MBO>;
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  FRL_LAUNCH(kern, dim3(tcn_grid(a.npix)), dim3(256), lds, st, (const T*)x, wc, bc, gw, gb, wg, bg, wp, bp, (T*)y, a);
+  FRL_LAUNCH(kern, dim3(tcn_grid(a.npix)), dim3(256), lds, st, (const T*)x, (const frag_t*)ws, bc, gw, gb, bg, wp ? 1 : 0, bp, (T*)y, a);
   return frl_check_launch("tcn_block_fwd");
 }
 
 template <typename T, int NFI, int MBO, int NFP>
 static int launch_tconv3(const void* x, const float* w, int64_t so, int64_t si, int rev, const void* r, const void* r2,
-                         const float* wp, int64_t pso, int64_t psi, int Cp, void* y, const TcnArgs& a, hipStream_t st) {
+                         const float* wp, int64_t pso, int64_t psi, int Cp, void* y, const TcnArgs& a, void* ws, size_t ws_bytes,
+                         hipStream_t st) {
   typedef typename DT<T>::frag_t frag_t;
   const size_t lds = (size_t)(3 * MBO * NFI + (wp ? MBO * NFP : 0)) * 64 * sizeof(frag_t);
   if (lds > 160 * 1024) return frl_fail(-3, "tconv3: weights exceed LDS");
+  if (ws == nullptr || ws_bytes < lds) return frl_fail(-4, "tconv3: workspace too small for the packed weights");
+  FRL_LAUNCH((tcn_pack_kernel<T, NFI, MBO, NFP>), dim3(32), dim3(256), 0, st, (frag_t*)ws, 2, w, so, si, rev, (const float*)nullptr, wp,
+             pso, psi, Cp, a.Cin, a.Cout);
   auto kern = tconv3_kernel<T, NFI, MBO, NFP>;
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  FRL_LAUNCH(kern, dim3(tcn_grid(a.npix)), dim3(256), lds, st, (const T*)x, w, so, si, rev, (const T*)r, (const T*)r2, wp, pso,
-                     psi, Cp, (T*)y, a);
+  FRL_LAUNCH(kern, dim3(tcn_grid(a.npix)), dim3(256), lds, st, (const T*)x, (const frag_t*)ws, (const T*)r, (const T*)r2, wp ? 1 : 0,
+             Cp, (T*)y, a);
   return frl_check_launch("tconv3");
 }
 
@@ -224,14 +229,15 @@ extern "C" {
 // (null <=> identity residual, requires Cin == Cout).  npix = B*HW.
 int frl_tcn_block_fwd(const void* x, const float* conv_w, const float* conv_b, const float* gn_w, const float* gn_b,
                       const float* gate_w, const float* gate_b, const float* proj_w, const float* proj_b, void* y, int64_t npix,
-                      int HW, int T, int Cin, int Cout, int dilation, int G, float eps, int dtype, hipStream_t stream) {
+                      int HW, int T, int Cin, int Cout, int dilation, int G, float eps, int dtype, void* ws, size_t ws_bytes,
+                      hipStream_t stream) {
   if (npix <= 0 || T <= 0) return frl_fail(-2, "tcn_block_fwd: empty input");
   if (proj_w == nullptr && Cin != Cout) return frl_fail(-2, "tcn_block_fwd: identity residual needs Cin == Cout");
   int rc = frl_tcn_check(Cin, Cout, G, dtype);
   if (rc) return rc;
   TcnArgs a{npix, HW, T, dilation, Cin, Cout, G, eps};
   const int pi = pad_class(Cin, dtype), po = pad_class(Cout, dtype);
-#define CALL(TT, NFI, MBO) return launch_tcn_fwd<TT, NFI, MBO>(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, y, a, stream);
+#define CALL(TT, NFI, MBO) return launch_tcn_fwd<TT, NFI, MBO>(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, y, a, ws, ws_bytes, stream);
   if (dtype == FRL_F32) TCN_SWITCH_F32(pi, po, CALL)
   else if (dtype == FRL_BF16) TCN_SWITCH_BF16(pi, po, CALL)
 #undef CALL
@@ -240,14 +246,14 @@ int frl_tcn_block_fwd(const void* x, const float* conv_w, const float* conv_b, c
 
 // dx [.. Cin] = conv^T(dconv [.. Cout]) + (proj_w ? proj_w^T dres : dres)
 int frl_tcn_block_bwd_data(const void* dconv, const void* dres, const float* conv_w, const float* proj_w, void* dx, int64_t npix, int HW,
-                           int T, int Cin, int Cout, int dilation, int dtype, hipStream_t stream) {
+                           int T, int Cin, int Cout, int dilation, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
   TcnArgs a{npix, HW, T, dilation, Cout, Cin, 1, 0.f};   // roles swapped: input width Cout, output width Cin
   const int pi = pad_class(Cout, dtype), po = pad_class(Cin, dtype);
   if (pi < 0 || po < 0) return frl_fail(-2, "tcn: channel counts above 128 unsupported");
   // Weff_k[o=ci][i=co] = conv_w[co][ci][2-k] -> so = 3, si = Cin*3, rev
   const void* r = proj_w ? nullptr : dres;
   const void* r2 = proj_w ? dres : nullptr;
-#define CALL(TT, NFI, MBO) return launch_tconv3<TT, NFI, MBO, NFI>(dconv, conv_w, 3, (int64_t)Cin * 3, 1, r, r2, proj_w, 1, Cin, Cout, dx, a, stream);
+#define CALL(TT, NFI, MBO) return launch_tconv3<TT, NFI, MBO, NFI>(dconv, conv_w, 3, (int64_t)Cin * 3, 1, r, r2, proj_w, 1, Cin, Cout, dx, a, ws, ws_bytes, stream);
   if (dtype == FRL_F32) TCN_SWITCH_F32(pi, po, CALL)
   else if (dtype == FRL_BF16) TCN_SWITCH_BF16(pi, po, CALL)
 #undef CALL

@@ -17,15 +17,17 @@
 // Roofline: HBM for K <= 1024 (algorithmic bytes/vector = 2*d*s + 4), MFMA for K = 8192.
 #include "frl_common.hpp"
 #include "frl_host.hpp"
+#include "frl_reduce.hpp"
 #include <math.h>
 
 #define VQ_IDX_BITS 9
 #define VQ_IDX_MASK 511u
 #define VQ_MAX_CHUNK 512
 
-struct VqHeader {           // lives at the start of the workspace
+struct VqHeader {           // lives at the start of the workspace (zeroed by hipMemsetAsync every call)
   unsigned enmax_bits;      // max_k ||e_k||^2 as f32 bits (atomicMax on positive floats)
-  unsigned pad[3];
+  int namb;                 // number of rows flagged for exact re-evaluation (append counter of amb_list)
+  double sq_fix;            // sum of squared errors of the re-evaluated rows
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -51,7 +53,8 @@ template <typename T, int NF, int NT>
 __global__ __launch_bounds__(256) void vq_assign_kernel(
     const T* __restrict__ Z, const float* __restrict__ E, const float* __restrict__ en_g, const VqHeader* __restrict__ hdr,
     int64_t N, int K, int d, int Kc, int32_t* __restrict__ idx_out, T* __restrict__ zq_out,
-    float* __restrict__ partial /*[grid*4]*/, int32_t* __restrict__ hist_slab /*[grid][K]*/) {
+    float* __restrict__ partial /*[grid*4]*/, int32_t* __restrict__ hist_slab /*[grid][K]*/, VqHeader* __restrict__ hdr_w,
+    int32_t* __restrict__ amb_list) {
   typedef typename DT<T>::frag_t frag_t;
   constexpr int FE = DT<T>::FE;
   constexpr int q = NF * FE;                 // channels per lane quarter
@@ -172,7 +175,10 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(
       const float s1 = __uint_as_float(g1[t] & ~VQ_IDX_MASK), s2 = __uint_as_float(g2[t] & ~VQ_IDX_MASK);
       const bool amb = !((s2 - s1) > thr[t]);   // also catches NaN
       if (row < N) {
-        if (kc == 0) idx_out[row] = amb ? (-1 - code) : code;
+        if (kc == 0) {
+          idx_out[row] = amb ? (-1 - code) : code;
+          if (amb) amb_list[atomicAdd(&hdr_w->namb, 1)] = (int32_t)row;
+        }
         if (!amb) {
           // gather z_q (rounded to T) for this lane's channel quarter, accumulate squared error
           const float* er = E + (int64_t)code * d + q * kc;
@@ -214,86 +220,92 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// exact float64 re-evaluation of flagged rows.  Each wave scans a fixed row range (deterministic).
+// exact re-evaluation of the flagged rows (one wave per row, grid-stride over the append list):
+//   pass 1: f32 direct-difference distances to all K codes -> wave minimum m32;
+//   pass 2: codes within the f32 rounding bound of m32 are re-evaluated in float64, first index wins ties.
+// Results per row are independent of the list order; the squared-error sum uses a float64 atomic.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void vq_fixup_kernel(const T* __restrict__ Z, const float* __restrict__ E, int64_t N,
-                                                       int K, int d, int64_t rows_per_wave, int32_t* __restrict__ idx_out,
-                                                       T* __restrict__ zq_out, float* __restrict__ partial_fix,
-                                                       int32_t* __restrict__ counts_fix, int32_t* __restrict__ namb) {
+__global__ __launch_bounds__(256) void vq_fixup_kernel(const T* __restrict__ Z, const float* __restrict__ E, int K, int d,
+                                                       const int32_t* __restrict__ amb_list, VqHeader* __restrict__ hdr,
+                                                       int32_t* __restrict__ idx_out, T* __restrict__ zq_out,
+                                                       int32_t* __restrict__ counts_fix) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* zrow = reinterpret_cast<double*>(smem) + (size_t)wave * d;
-  const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t r0 = gw * rows_per_wave;
-  int64_t r1 = r0 + rows_per_wave;
-  if (r1 > N) r1 = N;
-  float sq = 0.f;
-  int cnt = 0;
-  for (int64_t base = r0; base < r1; base += 64) {
-    const int64_t myrow = base + lane;
-    const int myidx = (myrow < r1) ? idx_out[myrow] : 0;
-    unsigned long long m = __ballot(myidx < 0);
-    while (m) {
-      const int bit = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      const int64_t n = base + bit;
-      for (int j = lane; j < d; j += 64) zrow[j] = (double)to_f32(Z[n * (int64_t)d + j]);
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      double best = 1.0e300;
-      int bestk = 0x7fffffff;
-      for (int k = lane; k < K; k += 64) {
-        const float* er = E + (int64_t)k * d;
-        double s = 0.0;
-        for (int j = 0; j < d; ++j) {
-          const double df = zrow[j] - (double)to_f32(from_f32<T>(er[j]));
-          s += df * df;
-        }
-        if (s < best) { best = s; bestk = k; }
-      }
+  float* zrow = reinterpret_cast<float*>(smem) + (size_t)wave * d;
+  const int namb = hdr->namb;
+  const int nwaves = gridDim.x * 4;
+  const float slack = 2.f * (float)(d + 8) * 1.1920929e-7f;
+  for (int it = blockIdx.x * 4 + wave; it < namb; it += nwaves) {
+    const int64_t n = amb_list[it];
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < d; j += 64) zrow[j] = to_f32(Z[n * (int64_t)d + j]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float m32 = 3.0e38f;
+    for (int k = lane; k < K; k += 64) {
+      const float* er = E + (int64_t)k * d;
+      float s = 0.f;
+      for (int j = 0; j < d; ++j) { const float df = zrow[j] - to_f32(from_f32<T>(er[j])); s = fmaf(df, df, s); }
+      m32 = fminf(m32, s);
+    }
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const double ob = __shfl_xor(best, off, 64);
-        const int ok = __shfl_xor(bestk, off, 64);
-        if (ob < best || (ob == best && ok < bestk)) { best = ob; bestk = ok; }
+    for (int off = 32; off > 0; off >>= 1) m32 = fminf(m32, __shfl_xor(m32, off, 64));
+    const float bound = m32 * (1.f + slack) + 1e-30f;
+    double best = 1.0e300;
+    int bestk = 0x7fffffff;
+    for (int k = lane; k < K; k += 64) {
+      const float* er = E + (int64_t)k * d;
+      float s = 0.f;
+      for (int j = 0; j < d; ++j) { const float df = zrow[j] - to_f32(from_f32<T>(er[j])); s = fmaf(df, df, s); }
+      if (s <= bound) {
+        double sd = 0.0;
+        for (int j = 0; j < d; ++j) { const double df = (double)zrow[j] - (double)to_f32(from_f32<T>(er[j])); sd += df * df; }
+        if (sd < best) { best = sd; bestk = k; }
       }
-      for (int j = lane; j < d; j += 64) {
-        const float ev = to_f32(from_f32<T>(E[(int64_t)bestk * d + j]));
-        zq_out[n * (int64_t)d + j] = from_f32<T>(ev);
-        const float df = (float)zrow[j] - ev;
-        sq = fmaf(df, df, sq);
-      }
-      if (lane == 0) { idx_out[n] = bestk; atomicAdd(&counts_fix[bestk], 1); }
-      ++cnt;
-      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_xor(best, off, 64);
+      const int ok = __shfl_xor(bestk, off, 64);
+      if (ob < best || (ob == best && ok < bestk)) { best = ob; bestk = ok; }
+    }
+    float sq = 0.f;
+    for (int j = lane; j < d; j += 64) {
+      const float ev = to_f32(from_f32<T>(E[(int64_t)bestk * d + j]));
+      zq_out[n * (int64_t)d + j] = from_f32<T>(ev);
+      const float df = zrow[j] - ev;
+      sq = fmaf(df, df, sq);
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) {
+      idx_out[n] = bestk;
+      atomicAdd(&counts_fix[bestk], 1);
+      atomicAdd(&hdr->sq_fix, (double)sq);
     }
   }
-  const float s = wave_sum(sq);
-  if (lane == 0) { partial_fix[gw] = s; if (cnt) atomicAdd(namb, cnt); }
 }
 
-// ---------------------------------------------------------------------------------------------
-// finalize: counts[k] = sum_wg hist + fix ; stats = {sqerr_sum, perplexity, n_ambiguous, 0}
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restrict__ partial, int npartial,
-                                                          const int32_t* __restrict__ hist_slab, int nslab, int K,
-                                                          const int32_t* __restrict__ counts_fix, const int32_t* namb,
-                                                          int64_t N, int32_t* __restrict__ counts_out, float* __restrict__ stats) {
+// histogram slabs -> counts (epilogue of the generic slab reduction)
+struct HistEpi {
+  const int32_t* counts_fix; int32_t* counts_out;
+  __device__ void operator()(int64_t i, int s) const { counts_out[i] = s + counts_fix[i]; }
+};
+
+// stats = {sqerr_sum, perplexity, n_re-evaluated, 0}
+__global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restrict__ partial, int npartial, const VqHeader* __restrict__ hdr,
+                                                          const int32_t* __restrict__ counts, int K, int64_t N, float* __restrict__ stats) {
   __shared__ double red[256];
   double s = 0.0;
   for (int i = threadIdx.x; i < npartial; i += 256) s += (double)partial[i];
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-  const double sq = red[0];
+  const double sq = red[0] + hdr->sq_fix;
   __syncthreads();
   double h = 0.0;
   for (int k = threadIdx.x; k < K; k += 256) {
-    int c = counts_fix[k];
-    for (int w = 0; w < nslab; ++w) c += hist_slab[(int64_t)w * K + k];
-    counts_out[k] = c;
-    const double p = (double)c / (double)N;
+    const double p = (double)counts[k] / (double)N;
     h += p * log(p + 1e-10);
   }
   red[threadIdx.x] = h;
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restric
   if (threadIdx.x == 0) {
     stats[0] = (float)sq;
     stats[1] = (float)exp(-red[0]);
-    stats[2] = (float)(*namb);
+    stats[2] = (float)hdr->namb;
     stats[3] = 0.f;
   }
 }
@@ -439,21 +451,19 @@ static int vq_grid(int64_t N, int NT) {
   return (int)(nb < 512 ? (nb < 1 ? 1 : nb) : 512);
 }
 #define VQ_NT 4
-#define VQ_FIX_WAVES 2048
+#define VQ_FIX_WAVES 1024
 #define VQ_BWD_WGS 128
 
-struct VqLayout { size_t hdr, en, partial, partial_fix, hist, counts_fix, namb, total; int grid; };
+struct VqLayout { size_t hdr, en, counts_fix, partial, amb, hist, total; int grid; };
 static VqLayout vq_layout(int64_t N, int K) {
   VqLayout L;
   L.grid = vq_grid(N, VQ_NT);
   size_t o = 0;
   L.hdr = o; o += 256;
+  L.counts_fix = o; o += ((size_t)K * 4 + 255) / 256 * 256;       // [hdr, counts_fix] are zeroed every call
   L.en = o; o += ((size_t)K * 4 + 255) / 256 * 256;
-  L.partial = o; o += (size_t)L.grid * 4 * 4;          // partial_fix follows contiguously (finalize sums both)
-  L.partial_fix = o; o += (size_t)VQ_FIX_WAVES * 4;
-  o = (o + 255) / 256 * 256;
-  L.counts_fix = o; o += ((size_t)K * 4 + 255) / 256 * 256;
-  L.namb = o; o += 256;
+  L.partial = o; o += ((size_t)L.grid * 4 * 4 + 255) / 256 * 256;
+  L.amb = o; o += ((size_t)N * 4 + 255) / 256 * 256;
   L.hist = o; o += (size_t)L.grid * K * 4;
   L.total = o;
   return L;
@@ -468,22 +478,19 @@ static int launch_vq(const void* z, const float* E, int64_t N, int K, int d, int
   const int Kc = vq_chunk(K, d_pad, sizeof(T));
   VqHeader* hdr = (VqHeader*)(ws + L.hdr);
   float* en = (float*)(ws + L.en);
-  // zero header, fixup counters (everything between hdr and hist)
-  FRL_HIP(hipMemsetAsync(ws, 0, L.hist, st));
+  FRL_HIP(hipMemsetAsync(ws, 0, L.en, st));                          // header + counts_fix
   FRL_LAUNCH((vq_prep_kernel<T>), dim3((K + 255) / 256), dim3(256), 0, st, E, K, d, en, hdr);
   const size_t lds = (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc * 4 + (size_t)K * 4;
   if (lds > 160 * 1024) return frl_fail(-3, "vq_assign: LDS budget exceeded (K too large for histogram)");
   auto kern = vq_assign_kernel<T, NF, VQ_NT>;
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   FRL_LAUNCH(kern, dim3(L.grid), dim3(256), lds, st, (const T*)z, E, en, hdr, N, K, d, Kc, idx, (T*)zq,
-                     (float*)(ws + L.partial), (int32_t*)(ws + L.hist));
-  const int64_t rpw = ((N + VQ_FIX_WAVES - 1) / VQ_FIX_WAVES + 63) / 64 * 64;
-  FRL_LAUNCH((vq_fixup_kernel<T>), dim3(VQ_FIX_WAVES / 4), dim3(256), (size_t)4 * d * sizeof(double), st,
-                     (const T*)z, E, N, K, d, rpw, idx, (T*)zq, (float*)(ws + L.partial_fix),
-                     (int32_t*)(ws + L.counts_fix), (int32_t*)(ws + L.namb));
-  FRL_LAUNCH(vq_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)(ws + L.partial),
-                     L.grid * 4 + VQ_FIX_WAVES, (const int32_t*)(ws + L.hist), L.grid, K,
-                     (const int32_t*)(ws + L.counts_fix), (const int32_t*)(ws + L.namb), N, counts, stats);
+             (float*)(ws + L.partial), (int32_t*)(ws + L.hist), hdr, (int32_t*)(ws + L.amb));
+  FRL_LAUNCH((vq_fixup_kernel<T>), dim3(VQ_FIX_WAVES / 4), dim3(256), (size_t)4 * d * sizeof(float), st, (const T*)z, E, K, d,
+             (const int32_t*)(ws + L.amb), hdr, idx, (T*)zq, (int32_t*)(ws + L.counts_fix));
+  launch_slab_reduce<int32_t, HistEpi>((const int32_t*)(ws + L.hist), L.grid, K, HistEpi{(const int32_t*)(ws + L.counts_fix), counts}, st);
+  FRL_LAUNCH(vq_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)(ws + L.partial), L.grid * 4, (const VqHeader*)hdr,
+             (const int32_t*)counts, K, N, stats);
   return frl_check_launch("vq_assign");
 }
 

@@ -28,8 +28,9 @@ SIGNATURES = {
     "frl_version": (c_int, []),
     "frl_last_error": (c_char_p, []),
     "frl_device_arch": (c_int, [c_char_p, I]),
-    "frl_conv1x1_fwd": (c_int, [P, P, P, P, L, I, I, I, I, P]),
-    "frl_conv1x1_bwd_data": (c_int, [P, P, I, P, P, L, I, I, I, P]),
+    "frl_conv_workspace_bytes": (S, [I, I, I]),
+    "frl_conv1x1_fwd": (c_int, [P, P, P, P, L, I, I, I, I, P, S, P]),
+    "frl_conv1x1_bwd_data": (c_int, [P, P, I, P, P, L, I, I, I, P, S, P]),
     "frl_conv1x1_bwd_weight_workspace_bytes": (S, [L, I, I]),
     "frl_conv1x1_bwd_weight": (c_int, [P, P, I, P, P, P, L, I, I, I, P, S, P]),
     "frl_conv_tap_bwd_weight": (c_int, [P, P, I, P, P, L, L, P, L, I, I, I, I, I, I, P, S, I, P]),
@@ -49,16 +50,16 @@ SIGNATURES = {
     "frl_gate_blend_bwd": (c_int, [P, P, P, P, F, P, P, L, I, P]),
     "frl_mean_time_fwd": (c_int, [P, P, L, I, L, I, P]),
     "frl_add": (c_int, [P, P, F, P, L, I, P]),
-    "frl_conv3x3_fwd": (c_int, [P, P, P, P, I, I, I, I, I, I, I, P]),
-    "frl_conv3x3_bwd_data": (c_int, [P, P, I, P, P, I, I, I, I, I, I, P]),
+    "frl_conv3x3_fwd": (c_int, [P, P, P, P, I, I, I, I, I, I, I, P, S, P]),
+    "frl_conv3x3_bwd_data": (c_int, [P, P, I, P, P, I, I, I, I, I, I, P, S, P]),
     "frl_conv3x3_bwd_weight_workspace_bytes": (S, [I, I, I, I, I]),
     "frl_conv3x3_bwd_weight": (c_int, [P, P, I, P, P, P, I, I, I, I, I, I, P, S, I, P]),
     "frl_sobel_fwd": (c_int, [P, P, I, I, I, I, I, P]),
     "frl_sobel_bwd": (c_int, [P, P, I, I, I, I, I, P]),
     "frl_edge_smooth_stencil_fwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "frl_edge_smooth_stencil_bwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
-    "frl_tcn_block_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, F, I, P]),
-    "frl_tcn_block_bwd_data": (c_int, [P, P, P, P, P, L, I, I, I, I, I, I, P]),
+    "frl_tcn_block_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, F, I, P, S, P]),
+    "frl_tcn_block_bwd_data": (c_int, [P, P, P, P, P, L, I, I, I, I, I, I, P, S, P]),
     "frl_tcn_block_bwd_workspace_bytes": (S, [L, I]),
     "frl_tcn_block_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, F, I, P, S, P]),
 }
@@ -73,6 +74,10 @@ def load():
         raise FrlHipError(
             f"{LIB_PATH} not found: build it with `python vq-vae_amd/build.py` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # PyTorch bundles its own libamdhip64 (same soname): it must be loaded FIRST so that libfrlhip.so binds to the
+    # runtime that owns torch's device pointers and streams.  Loading ours first leaves two HIP runtimes in the process
+    # and every launch fails with hipErrorNoDevice.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the header and library drift apart

@@ -100,8 +100,10 @@ def conv1x1_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], 
     w = _f32(w.reshape(cout, cin), "w")
     y = torch.empty(x.shape[:-1] + (cout,), dtype=x.dtype, device=x.device)
     p = x.numel() // cin
-    check(_lib.load().frl_conv1x1_fwd(_p(x), _p(w), _p(_f32(bias, "bias")), _p(y), p, cin, cout, act, _dt(x), _stream()),
-          "frl_conv1x1_fwd")
+    lib = _lib.load()
+    ws = workspace(lib.frl_conv_workspace_bytes(cin, cout, 1), x.device)
+    check(lib.frl_conv1x1_fwd(_p(x), _p(w), _p(_f32(bias, "bias")), _p(y), p, cin, cout, act, _dt(x), _p(ws), ws.numel(),
+                              _stream()), "frl_conv1x1_fwd")
     return y
 
 
@@ -112,7 +114,9 @@ def conv1x1_bwd_data(dy: torch.Tensor, w: torch.Tensor, y: Optional[torch.Tensor
     w = _f32(w.reshape(cout, cin), "w")
     dx = torch.empty(dy.shape[:-1] + (cin,), dtype=dy.dtype, device=dy.device)
     p = dy.numel() // cout
-    check(_lib.load().frl_conv1x1_bwd_data(_p(dy), _p(y), act, _p(w), _p(dx), p, cin, cout, _dt(dy), _stream()),
+    lib = _lib.load()
+    ws = workspace(lib.frl_conv_workspace_bytes(cin, cout, 1), dy.device)
+    check(lib.frl_conv1x1_bwd_data(_p(dy), _p(y), act, _p(w), _p(dx), p, cin, cout, _dt(dy), _p(ws), ws.numel(), _stream()),
           "frl_conv1x1_bwd_data")
     return dx
 
@@ -302,8 +306,10 @@ def conv3x3_fwd(x, w, bias, act: int = ACT_NONE):
     cout = w.shape[0]
     _chk_rows(x, cin, "conv3x3.x")
     y = torch.empty(b, h, wd, cout, dtype=x.dtype, device=x.device)
-    check(_lib.load().frl_conv3x3_fwd(_p(x), _p(_f32(w, "w")), _p(_f32(bias, "bias")), _p(y), b, h, wd, cin, cout, act,
-                                      _dt(x), _stream()), "frl_conv3x3_fwd")
+    lib = _lib.load()
+    ws = workspace(lib.frl_conv_workspace_bytes(cin, cout, 9), x.device)
+    check(lib.frl_conv3x3_fwd(_p(x), _p(_f32(w, "w")), _p(_f32(bias, "bias")), _p(y), b, h, wd, cin, cout, act, _dt(x), _p(ws),
+                              ws.numel(), _stream()), "frl_conv3x3_fwd")
     return y
 
 
@@ -312,8 +318,10 @@ def conv3x3_bwd_data(dy, w, y=None, act: int = ACT_NONE):
     b, h, wd, cout = dy.shape
     cin = w.shape[1]
     dx = torch.empty(b, h, wd, cin, dtype=dy.dtype, device=dy.device)
-    check(_lib.load().frl_conv3x3_bwd_data(_p(dy), _p(y), act, _p(_f32(w, "w")), _p(dx), b, h, wd, cin, cout, _dt(dy),
-                                           _stream()), "frl_conv3x3_bwd_data")
+    lib = _lib.load()
+    ws = workspace(lib.frl_conv_workspace_bytes(cin, cout, 9), dy.device)
+    check(lib.frl_conv3x3_bwd_data(_p(dy), _p(y), act, _p(_f32(w, "w")), _p(dx), b, h, wd, cin, cout, _dt(dy), _p(ws),
+                                   ws.numel(), _stream()), "frl_conv3x3_bwd_data")
     return dx
 
 
@@ -381,10 +389,12 @@ def tcn_block_fwd(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b,
     cout = conv_w.shape[0]
     hw = x.numel() // (b * t * cin)
     y = torch.empty(x.shape[:-1] + (cout,), dtype=x.dtype, device=x.device)
-    check(_lib.load().frl_tcn_block_fwd(_p(x), _p(_f32(conv_w, "conv_w")), _p(conv_b), _p(gn_w), _p(gn_b),
-                                        _p(_f32(gate_w.reshape(cout, cout), "gate_w")), _p(gate_b), _p(proj_w), _p(proj_b),
-                                        _p(y), b * hw, hw, t, cin, cout, dilation, groups, float(eps), _dt(x), _stream()),
-          "frl_tcn_block_fwd")
+    lib = _lib.load()
+    ws = workspace(lib.frl_conv_workspace_bytes(max(cin, cout), cout, 6), x.device)
+    check(lib.frl_tcn_block_fwd(_p(x), _p(_f32(conv_w, "conv_w")), _p(conv_b), _p(gn_w), _p(gn_b),
+                                _p(_f32(gate_w.reshape(cout, cout), "gate_w")), _p(gate_b), _p(proj_w), _p(proj_b),
+                                _p(y), b * hw, hw, t, cin, cout, dilation, groups, float(eps), _dt(x), _p(ws), ws.numel(),
+                                _stream()), "frl_tcn_block_fwd")
     return y
 
 
@@ -409,8 +419,9 @@ def tcn_block_bwd(x, dy, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, pro
                                 _p(proj_b), _p(dconv), _p(dgpre), _p(normed), _p(dres), _p(dgam), _p(dbet), npix, hw, t, cin,
                                 cout, dilation, groups, float(eps), _dt(x), _p(ws), ws.numel(), _stream()), "frl_tcn_block_bwd")
     dx = torch.empty_like(x)
+    ws1 = workspace(lib.frl_conv_workspace_bytes(max(cin, cout), max(cin, cout), 6), dev)
     check(lib.frl_tcn_block_bwd_data(_p(dconv), _p(dres), _p(conv_w), _p(proj_w), _p(dx), npix, hw, t, cin, cout, dilation,
-                                     _dt(x), _stream()), "frl_tcn_block_bwd_data")
+                                     _dt(x), _p(ws1), ws1.numel(), _stream()), "frl_tcn_block_bwd_data")
     p = b * t * hw
     dw = torch.empty(cout, cin, 3, dtype=torch.float32, device=dev)
     dcb = torch.empty(cout, dtype=torch.float32, device=dev)
