@@ -194,7 +194,7 @@ struct WgradEpi {
 
 static int wgrad_nwg(int64_t P) {
   int64_t n = (P + WG_KP - 1) / WG_KP;
-  if (n > 256) n = 256;
+  if (n > 1024) n = 1024;
   if (n < 1) n = 1;
   return (int)n;
 }

@@ -5,11 +5,17 @@
 // Outputs feed the MFMA weight-gradient kernels (pw_wgrad.hip): dconv (3 temporal taps against x), dgpre against the
 // normalised features `normed`, dres against x (projection only); d gamma / d beta are reduced in fixed order.
 // dx itself is produced by frl_tcn_block_bwd_data (conv^T over dconv + residual path).
+// The pixel's time series is cached in registers (TP time steps, one batch of loads per tile); per-channel constants
+// live in an LDS table.
 #include "tcn_common.hpp"
 #include "frl_host.hpp"
 #include "frl_reduce.hpp"
 
-template <typename T, int NFI, int MBO>
+template <typename T, int NFI, int TP> constexpr bool tcn_tp_ok_b() {
+  return TP == 0 || (NFI * DT<T>::FE * 4 == 64 && TP * NFI * (int)sizeof(typename DT<T>::frag_t) / 4 <= 80);
+}
+
+template <typename T, int NFI, int MBO, int TP, int DIL>
 __global__ __launch_bounds__(256) void tcn_block_bwd_kernel(const T* __restrict__ X, const T* __restrict__ DY,
                                                             const typename DT<T>::frag_t* __restrict__ Wpk,
                                                             const float* __restrict__ bc, const float* __restrict__ gn_w,
@@ -26,29 +32,30 @@ __global__ __launch_bounds__(256) void tcn_block_bwd_kernel(const T* __restrict_
   frag_t* wl_gate = wl_conv + 3 * MBO * NFI * 64;                   // [MBO][NFO][64]
   frag_t* wl_gateT = wl_gate + MBO * NFO * 64;                      // [MBO][NFO][64]  (Wg^T)
   frag_t* wl_proj = wl_gateT + MBO * NFO * 64;                      // [MBO][NFI][64]
+  float* tab = reinterpret_cast<float*>(wl_proj + (has_proj ? MBO * NFI * 64 : 0));   // gw | gb | gbias | pb, each [4*Q]
+  float* gacc_lds = tab + 16 * Q;                         // [4 waves][2][4*Q]: per-wave d gamma / d beta accumulators
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, kc = lane >> 4;
   copy_frags_lds<T>(wl_conv, Wpk, (3 * MBO * NFI + 2 * MBO * NFO + (has_proj ? MBO * NFI : 0)) * 64, tid, 256);
+  for (int i = tid; i < 4 * Q; i += 256) {
+    const bool ok = i < a.Cout;
+    tab[i] = ok ? gn_w[i] : 0.f;
+    tab[4 * Q + i] = ok ? gn_b[i] : 0.f;
+    tab[8 * Q + i] = ok ? bg[i] : 0.f;
+    tab[12 * Q + i] = (ok && has_proj) ? bp[i] : 0.f;
+  }
+  for (int i = tid; i < 4 * 2 * 4 * Q; i += 256) gacc_lds[i] = 0.f;
   __syncthreads();
-  const float* Wp = has_proj ? bp : nullptr;   // non-null marker for the projection branches below
+  float* my_dg = gacc_lds + (wave * 2 + 0) * 4 * Q + Q * kc;
+  float* my_db = gacc_lds + (wave * 2 + 1) * 4 * Q + Q * kc;
+  const float* tgw = tab + Q * kc;
+  const float* tgb = tab + 4 * Q + Q * kc;
+  const float* tbg = tab + 8 * Q + Q * kc;
+  const float* tpb = tab + 12 * Q + Q * kc;
 
   const bool fast_in = (a.Cin == 4 * NFI * FE), fast_out = (a.Cout == 4 * Q);
   const int cg = a.Cout / a.G;
   const float inv_n = 1.f / ((float)cg * (float)a.Tn);
-  float dgam[Q], dbet[Q];
-#pragma unroll
-  for (int j = 0; j < Q; ++j) { dgam[j] = 0.f; dbet[j] = 0.f; }
-  float gw[Q], gb[Q], gbias[Q], cb[Q];
-#pragma unroll
-  for (int j = 0; j < Q; ++j) {
-    const int c = Q * kc + j;
-    const bool ok = c < a.Cout;
-    gw[j] = ok ? gn_w[c] : 0.f;
-    gb[j] = ok ? gn_b[c] : 0.f;
-    gbias[j] = ok ? bg[c] : 0.f;
-    cb[j] = ok ? bc[c] : 0.f;
-  }
-
   const int64_t ntile = (a.npix + 15) >> 4;
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
     int64_t pidx = tile * 16 + px;
@@ -57,10 +64,10 @@ __global__ __launch_bounds__(256) void tcn_block_bwd_kernel(const T* __restrict_
     if (!valid) pidx = a.npix - 1;
     const int64_t b = pidx / a.HW, hw = pidx % a.HW;
     const int64_t row0 = b * a.Tn * a.HW + hw;
-    float mean[Q], rstd[Q];
-    tcn_stats<T, NFI, MBO>(mean, rstd, X, row0, a, kc, fast_in, wl_conv, bc, lane);
-#pragma unroll
-    for (int j = 0; j < Q; ++j) mean[j] -= cb[j];       // fold the conv bias: xhat = (acc - mean) * rstd
+    XCache<T, NFI, TP> xc;
+    xcache_load<T, NFI, TP>(xc, X, row0, a, a.Cin, kc, fast_in);
+    float rs[Q], sh[Q];                                   // xhat = acc * rs + sh
+    tcn_stats<T, NFI, MBO, TP>(rs, sh, xc, X, row0, a, kc, fast_in, wl_conv, bc, lane);
     float S1[Q], S2[Q];
 #pragma unroll
     for (int j = 0; j < Q; ++j) { S1[j] = 0.f; S2[j] = 0.f; }
@@ -70,10 +77,10 @@ __global__ __launch_bounds__(256) void tcn_block_bwd_kernel(const T* __restrict_
       f32x4 acc[MBO];
 #pragma unroll
       for (int m = 0; m < MBO; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      tconv_at<T, NFI, MBO>(acc, X, row0, a, t, a.Cin, kc, fast_in, wl_conv, lane);
+      tconv_at<T, NFI, MBO, TP>(acc, xc, X, row0, a, t, a.Cin, kc, fast_in, wl_conv, lane);
       float xh[Q], n[Q];
 #pragma unroll
-      for (int j = 0; j < Q; ++j) { xh[j] = (acc[j >> 2][j & 3] - mean[j]) * rstd[j]; n[j] = fmaf(xh[j], gw[j], gb[j]); }
+      for (int j = 0; j < Q; ++j) { xh[j] = fmaf(acc[j >> 2][j & 3], rs[j], sh[j]); n[j] = fmaf(xh[j], tgw[j], tgb[j]); }
       LQTile<T, NFO> nt;
       acc_to_tile<T, MBO>(nt, n);
       f32x4 gacc[MBO];
@@ -81,15 +88,15 @@ __global__ __launch_bounds__(256) void tcn_block_bwd_kernel(const T* __restrict_
       for (int m = 0; m < MBO; ++m) gacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
       pw_at<T, NFO, MBO>(gacc, nt, wl_gate, lane);
       LQTile<T, NFI> xt;
-      lq_load<T, NFI>(xt, X, row, a.Cin, kc, fast_in);
+      xcache_get<T, NFI, TP>(xt, xc, X, row0, a, t, a.Cin, kc, fast_in);
       float res[Q];
-      if (Wp != nullptr) {
+      if (has_proj) {
         f32x4 pacc[MBO];
 #pragma unroll
         for (int m = 0; m < MBO; ++m) pacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
         pw_at<T, NFI, MBO>(pacc, xt, wl_proj, lane);
 #pragma unroll
-        for (int j = 0; j < Q; ++j) { const int c = Q * kc + j; res[j] = pacc[j >> 2][j & 3] + (c < a.Cout ? bp[c] : 0.f); }
+        for (int j = 0; j < Q; ++j) res[j] = pacc[j >> 2][j & 3] + tpb[j];
       } else {
         if constexpr (NFI * FE == Q) {
 #pragma unroll
@@ -101,14 +108,14 @@ __global__ __launch_bounds__(256) void tcn_block_bwd_kernel(const T* __restrict_
       }
       LQTile<T, NFO> dyt;
       lq_load<T, NFO>(dyt, DY, row, a.Cout, kc, fast_out);
-      float dgp[Q], dr[Q], dn[Q];
+      float dgp[Q], dn[Q];
 #pragma unroll
       for (int j = 0; j < Q; ++j) {
         const float dy = lq_get<T, NFO>(dyt, j / FE, j % FE) * vf;
-        const float g = 1.f / (1.f + expf(-(gacc[j >> 2][j & 3] + gbias[j])));
+        const float g = 1.f / (1.f + expf(-(gacc[j >> 2][j & 3] + tbg[j])));
         const float o = n[j] > 0.f ? n[j] : 0.f;
         dgp[j] = dy * (o - res[j]) * g * (1.f - g);
-        dr[j] = dy * (1.f - g);
+        res[j] = dy * (1.f - g);                      // reuse as d res
         dn[j] = n[j] > 0.f ? dy * g : 0.f;
       }
       LQTile<T, NFO> gt;
@@ -120,17 +127,15 @@ __global__ __launch_bounds__(256) void tcn_block_bwd_kernel(const T* __restrict_
 #pragma unroll
       for (int j = 0; j < Q; ++j) {
         dn[j] += bacc[j >> 2][j & 3];
-        const float dxh = dn[j] * gw[j];
+        const float dxh = dn[j] * tgw[j];
         S1[j] += dxh;
         S2[j] = fmaf(dxh, xh[j], S2[j]);
-        dgam[j] = fmaf(dn[j], xh[j], dgam[j]);
-        dbet[j] += dn[j];
       }
       if (valid) {
         lq_store<T, NFO>(nt, NORMED, row, a.Cout, kc, fast_out);
         lq_store<T, NFO>(gt, DGPRE, row, a.Cout, kc, fast_out);
         LQTile<T, NFO> tt;
-        acc_to_tile<T, MBO>(tt, dr);
+        acc_to_tile<T, MBO>(tt, res);
         lq_store<T, NFO>(tt, DRES, row, a.Cout, kc, fast_out);
         acc_to_tile<T, MBO>(tt, dn);
         lq_store<T, NFO>(tt, DCONV, row, a.Cout, kc, fast_out);      // temporary: dn, rewritten below
@@ -140,21 +145,27 @@ __global__ __launch_bounds__(256) void tcn_block_bwd_kernel(const T* __restrict_
     group_combine<Q>(m1, S1, cg);
     group_combine<Q>(m2, S2, cg);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own dn stores have landed before they are re-read
-    // ---------------- pass 3: GroupNorm backward -> dconv ----------------
+    // ---------------- pass 3: GroupNorm backward -> dconv ; d gamma / d beta of this tile ----------------
+    float dgam[Q], dbet[Q];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) { dgam[j] = 0.f; dbet[j] = 0.f; }
     for (int t = 0; t < a.Tn; ++t) {
       const int64_t row = row0 + (int64_t)t * a.HW;
       f32x4 acc[MBO];
 #pragma unroll
       for (int m = 0; m < MBO; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      tconv_at<T, NFI, MBO>(acc, X, row0, a, t, a.Cin, kc, fast_in, wl_conv, lane);
+      tconv_at<T, NFI, MBO, TP>(acc, xc, X, row0, a, t, a.Cin, kc, fast_in, wl_conv, lane);
       LQTile<T, NFO> dnt;
       lq_load<T, NFO>(dnt, DCONV, row, a.Cout, kc, fast_out);
       float dc[Q];
 #pragma unroll
       for (int j = 0; j < Q; ++j) {
-        const float xh = (acc[j >> 2][j & 3] - mean[j]) * rstd[j];
-        const float dxh = lq_get<T, NFO>(dnt, j / FE, j % FE) * gw[j];
-        dc[j] = rstd[j] * (dxh - m1[j] * inv_n - xh * m2[j] * inv_n);
+        const float xh = fmaf(acc[j >> 2][j & 3], rs[j], sh[j]);
+        const float dnv = lq_get<T, NFO>(dnt, j / FE, j % FE) * vf;
+        const float dxh = dnv * tgw[j];
+        dc[j] = rs[j] * (dxh - m1[j] * inv_n - xh * m2[j] * inv_n);
+        dgam[j] = fmaf(dnv, xh, dgam[j]);
+        dbet[j] += dnv;
       }
       if (valid) {
         LQTile<T, NFO> tt;
@@ -162,24 +173,23 @@ __global__ __launch_bounds__(256) void tcn_block_bwd_kernel(const T* __restrict_
         lq_store<T, NFO>(tt, DCONV, row, a.Cout, kc, fast_out);
       }
     }
-  }
-  // ---------------- d gamma / d beta: reduce over the 16 pixel lanes, the 4 waves, write the workgroup slab ----------------
-  float* red = reinterpret_cast<float*>(smem);            // reuse LDS (weights no longer needed)
-  __syncthreads();
+    // reduce this tile's d gamma / d beta over the 16 pixel lanes and accumulate in the wave's private LDS rows
 #pragma unroll
-  for (int j = 0; j < Q; ++j) {
+    for (int j = 0; j < Q; ++j) {
 #pragma unroll
-    for (int off = 1; off < 16; off <<= 1) { dgam[j] += __shfl_xor(dgam[j], off, 64); dbet[j] += __shfl_xor(dbet[j], off, 64); }
+      for (int off = 1; off < 16; off <<= 1) { dgam[j] += __shfl_xor(dgam[j], off, 64); dbet[j] += __shfl_xor(dbet[j], off, 64); }
+    }
     if (px == 0) {
-      red[(wave * 2 + 0) * 4 * Q + Q * kc + j] = dgam[j];
-      red[(wave * 2 + 1) * 4 * Q + Q * kc + j] = dbet[j];
+#pragma unroll
+      for (int j = 0; j < Q; ++j) { my_dg[j] += dgam[j]; my_db[j] += dbet[j]; }
     }
   }
+  // ---------------- d gamma / d beta: sum the 4 per-wave LDS accumulators, write the workgroup slab ----------------
   __syncthreads();
   for (int i = tid; i < 2 * a.Cout; i += 256) {
     const int which = i / a.Cout, c = i % a.Cout;
     float s = 0.f;
-    for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * 4 * Q + c];
+    for (int w = 0; w < 4; ++w) s += gacc_lds[(w * 2 + which) * 4 * Q + c];
     slab[(int64_t)blockIdx.x * 2 * a.Cout + i] = s;
   }
 }
@@ -196,24 +206,40 @@ struct TcnGbEpi {
   __device__ void operator()(int64_t i, float s) const { if (i < n) dgamma[i] = s; else dbeta[i - n] = s; }
 };
 
+template <typename T, int NFI, int MBO, int TP, int DIL>
+static int launch_tcn_bwd_tp(const void* x, const void* dy, const void* pk, const float* bc, const float* gw, const float* gb,
+                             const float* bg, const float* wp, const float* bp, void* dconv, void* dgpre, void* normed, void* dres,
+                             float* ws, const TcnArgs& a, unsigned grid, size_t lds, hipStream_t st) {
+  typedef typename DT<T>::frag_t frag_t;
+  if constexpr (tcn_tp_ok_b<T, NFI, TP>()) {
+    auto kern = tcn_block_bwd_kernel<T, NFI, MBO, TP, DIL>;
+    if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FRL_LAUNCH(kern, dim3(grid), dim3(256), lds, st, (const T*)x, (const T*)dy, (const frag_t*)pk, bc, gw, gb, bg, wp ? 1 : 0, bp,
+               (T*)dconv, (T*)dgpre, (T*)normed, (T*)dres, ws, a);
+    return 0;
+  } else {
+    return launch_tcn_bwd_tp<T, NFI, MBO, 0, 0>(x, dy, pk, bc, gw, gb, bg, wp, bp, dconv, dgpre, normed, dres, ws, a, grid, lds, st);
+  }
+}
+
 template <typename T, int NFI, int MBO>
 static int launch_tcn_bwd(const void* x, const void* dy, const float* wc, const float* bc, const float* gw, const float* gb, const float* wg,
                           const float* bg, const float* wp, const float* bp, void* dconv, void* dgpre, void* normed, void* dres,
                           float* dgamma, float* dbeta, float* ws, const TcnArgs& a, hipStream_t st) {
   typedef typename DT<T>::frag_t frag_t;
   constexpr int NFO = 4 * MBO / DT<T>::FE;
-  size_t lds = (size_t)(3 * MBO * NFI + 2 * MBO * NFO + (wp ? MBO * NFI : 0)) * 64 * sizeof(frag_t);
-  const size_t red = (size_t)8 * 16 * MBO * sizeof(float);
-  if (lds < red) lds = red;
+  size_t lds = (size_t)(3 * MBO * NFI + 2 * MBO * NFO + (wp ? MBO * NFI : 0)) * 64 * sizeof(frag_t) + (size_t)(16 + 32) * 4 * MBO * sizeof(float);
   if (lds > 160 * 1024) return frl_fail(-3, "tcn_block_bwd: weights exceed LDS");
-  auto kern = tcn_block_bwd_kernel<T, NFI, MBO>;
-  if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned grid = tcn_bwd_grid(a.npix);
   frag_t* pk = reinterpret_cast<frag_t*>(reinterpret_cast<char*>(ws) + (((size_t)grid * 2 * a.Cout * sizeof(float) + 255) / 256) * 256);
   FRL_LAUNCH((tcn_pack_kernel<T, NFI, MBO, NFI>), dim3(32), dim3(256), 0, st, pk, 1, wc, (int64_t)a.Cin * 3, (int64_t)3, 0, wg, wp,
              (int64_t)a.Cin, (int64_t)1, a.Cin, a.Cin, a.Cout);
-  FRL_LAUNCH(kern, dim3(grid), dim3(256), lds, st, (const T*)x, (const T*)dy, (const frag_t*)pk, bc, gw, gb, bg, wp ? 1 : 0, bp, (T*)dconv,
-             (T*)dgpre, (T*)normed, (T*)dres, ws, a);
+  int rc;
+#define BWD_TP(D) launch_tcn_bwd_tp<T, NFI, MBO, 5, D>(x, dy, pk, bc, gw, gb, bg, wp, bp, dconv, dgpre, normed, dres, ws, a, grid, lds, st)
+  if (a.Tn <= 5) rc = BWD_TP(0);
+  else rc = launch_tcn_bwd_tp<T, NFI, MBO, 0, 0>(x, dy, pk, bc, gw, gb, bg, wp, bp, dconv, dgpre, normed, dres, ws, a, grid, lds, st);
+#undef BWD_TP
+  if (rc) return rc;
   launch_slab_reduce<float, TcnGbEpi>((const float*)ws, (int)grid, 2 * a.Cout, TcnGbEpi{a.Cout, dgamma, dbeta}, st);
   return frl_check_launch("tcn_block_bwd");
 }

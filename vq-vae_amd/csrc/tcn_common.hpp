@@ -7,6 +7,8 @@
 //   * the GroupNorm over (C/G channels x T) of one pixel is an in-lane reduction,
 //   * the accumulator image of conv / gate GEMMs is again a lane-quarter image (see frl_common.hpp), so the
 //     normalised features feed the gate GEMM and the block output feeds HBM with no LDS transpose.
+// With TP > 0 the pixel's whole time series (TP time steps) is loaded ONCE per tile into registers in a single batch
+// of 16-byte loads (one memory latency per tile instead of one per tap), and every conv pass reuses it.
 #pragma once
 #include "frl_common.hpp"
 
@@ -17,20 +19,59 @@ struct TcnArgs {
   float eps;
 };
 
+// register cache of one pixel's time series (lane-quarter images for t = 0..TP-1)
+template <typename T, int NFI, int TP> struct XCache { LQTile<T, NFI> xs[TP > 0 ? TP : 1]; };
+
+template <typename T, int NFI, int TP>
+__device__ __forceinline__ void xcache_load(XCache<T, NFI, TP>& xc, const T* __restrict__ X, int64_t row0, const TcnArgs& a, int C,
+                                            int kc, bool fast) {
+  if constexpr (TP > 0) {
+#pragma unroll
+    for (int u = 0; u < TP; ++u)
+      if (u < a.Tn) lq_load<T, NFI>(xc.xs[u], X, row0 + (int64_t)u * a.HW, C, kc, fast);
+  }
+}
+
+// lane-quarter image of time step t (t is wave-uniform): from the register cache or straight from memory
+template <typename T, int NFI, int TP>
+__device__ __forceinline__ void xcache_get(LQTile<T, NFI>& o, const XCache<T, NFI, TP>& xc, const T* __restrict__ X, int64_t row0,
+                                           const TcnArgs& a, int t, int C, int kc, bool fast) {
+  if constexpr (TP > 0) {
+#pragma unroll
+    for (int u = 0; u < TP; ++u)
+      if (u == t) o = xc.xs[u];
+  } else {
+    lq_load<T, NFI>(o, X, row0 + (int64_t)t * a.HW, C, kc, fast);
+  }
+}
+
 // conv output (no bias) for time t of this lane's pixel: 3 taps at t-d, t, t+d (zero padded in time)
-template <typename T, int NFI, int MBO>
-__device__ __forceinline__ void tconv_at(f32x4 (&acc)[MBO], const T* __restrict__ X, int64_t row0, const TcnArgs& a, int t, int C,
-                                         int kc, bool fast, const typename DT<T>::frag_t* __restrict__ wl, int lane) {
+template <typename T, int NFI, int MBO, int TP>
+__device__ __forceinline__ void tconv_at(f32x4 (&acc)[MBO], const XCache<T, NFI, TP>& xc, const T* __restrict__ X, int64_t row0,
+                                         const TcnArgs& a, int t, int C, int kc, bool fast,
+                                         const typename DT<T>::frag_t* __restrict__ wl, int lane) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const int tin = t + (k - 1) * a.dil;
     if (tin < 0 || tin >= a.Tn) continue;
-    LQTile<T, NFI> xt;
-    lq_load<T, NFI>(xt, X, row0 + (int64_t)tin * a.HW, C, kc, fast);
+    if constexpr (TP > 0) {
 #pragma unroll
-    for (int m = 0; m < MBO; ++m)
+      for (int u = 0; u < TP; ++u) {
+        if (u == tin) {
 #pragma unroll
-      for (int s = 0; s < NFI; ++s) acc[m] = mfma16(wl[((k * MBO + m) * NFI + s) * 64 + lane], xt.f[s], acc[m]);
+          for (int m = 0; m < MBO; ++m)
+#pragma unroll
+            for (int s = 0; s < NFI; ++s) acc[m] = mfma16(wl[((k * MBO + m) * NFI + s) * 64 + lane], xc.xs[u].f[s], acc[m]);
+        }
+      }
+    } else {
+      LQTile<T, NFI> xt;
+      lq_load<T, NFI>(xt, X, row0 + (int64_t)tin * a.HW, C, kc, fast);
+#pragma unroll
+      for (int m = 0; m < MBO; ++m)
+#pragma unroll
+        for (int s = 0; s < NFI; ++s) acc[m] = mfma16(wl[((k * MBO + m) * NFI + s) * 64 + lane], xt.f[s], acc[m]);
+    }
   }
 }
 
@@ -100,31 +141,30 @@ __device__ __forceinline__ void group_first(float (&out)[Q], const float (&in)[Q
   }
 }
 
-// Per-lane GroupNorm statistics of the conv output over (group channels x T), shifted sums for accuracy.
-// Produces mean[j], rstd[j] for the lane's Q = 4*MBO channels (identical within a group).
-template <typename T, int NFI, int MBO>
-__device__ __forceinline__ void tcn_stats(float (&mean)[4 * MBO], float (&rstd)[4 * MBO], const T* __restrict__ X, int64_t row0,
-                                          const TcnArgs& a, int kc, bool fast, const typename DT<T>::frag_t* __restrict__ wl_conv,
-                                          const float* __restrict__ bias, int lane) {
+// Per-lane GroupNorm statistics of the conv output c = acc + bias over (group channels x T), shifted sums for accuracy.
+// Produces for the lane's Q = 4*MBO channels:  scale[j] = rstd,  shiftv[j] = (bias_j - mean_group) * rstd  so that
+//   xhat = acc * scale + shiftv   (acc = bias-free MFMA accumulator).
+template <typename T, int NFI, int MBO, int TP>
+__device__ __forceinline__ void tcn_stats(float (&scale)[4 * MBO], float (&shiftv)[4 * MBO], const XCache<T, NFI, TP>& xc,
+                                          const T* __restrict__ X, int64_t row0, const TcnArgs& a, int kc, bool fast,
+                                          const typename DT<T>::frag_t* __restrict__ wl_conv, const float* __restrict__ bias,
+                                          int lane) {
   constexpr int Q = 4 * MBO;
   const int cg = a.Cout / a.G;
-  float shift[Q], s1[Q], s2[Q];
+  float shift[Q], s1[Q], s2[Q], cb[Q];
+#pragma unroll
+  for (int j = 0; j < Q; ++j) cb[j] = (Q * kc + j < a.Cout) ? bias[Q * kc + j] : 0.f;
+#pragma unroll
+  for (int j = 0; j < Q; ++j) { shift[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
   for (int t = 0; t < a.Tn; ++t) {
     f32x4 acc[MBO];
 #pragma unroll
     for (int m = 0; m < MBO; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    tconv_at<T, NFI, MBO>(acc, X, row0, a, t, a.Cin, kc, fast, wl_conv, lane);
+    tconv_at<T, NFI, MBO, TP>(acc, xc, X, row0, a, t, a.Cin, kc, fast, wl_conv, lane);
     float v[Q];
 #pragma unroll
-    for (int j = 0; j < Q; ++j) {
-      const int c = Q * kc + j;
-      v[j] = acc[j >> 2][j & 3] + (c < a.Cout ? bias[c] : 0.f);
-    }
-    if (t == 0) {
-      group_first<Q>(shift, v, cg);
-#pragma unroll
-      for (int j = 0; j < Q; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    }
+    for (int j = 0; j < Q; ++j) v[j] = acc[j >> 2][j & 3] + cb[j];
+    if (t == 0) group_first<Q>(shift, v, cg);
 #pragma unroll
     for (int j = 0; j < Q; ++j) { const float d = v[j] - shift[j]; s1[j] += d; s2[j] = fmaf(d, d, s2[j]); }
   }
@@ -137,8 +177,9 @@ __device__ __forceinline__ void tcn_stats(float (&mean)[4 * MBO], float (&rstd)[
     const float md = g1[j] * inv_n;
     float var = g2[j] * inv_n - md * md;
     var = var > 0.f ? var : 0.f;
-    mean[j] = shift[j] + md;
-    rstd[j] = 1.f / sqrtf(var + a.eps);
+    const float rs = 1.f / sqrtf(var + a.eps);
+    scale[j] = rs;
+    shiftv[j] = (cb[j] - (shift[j] + md)) * rs;
   }
 }
 
@@ -161,3 +202,6 @@ __global__ void tcn_pack_kernel(typename DT<T>::frag_t* __restrict__ dst, int mo
   if (Wp != nullptr) pack_weights_lds<T, NFP>(p, Wp, Cout, Cp, MBO, pso, psi, tid, nt);
 }
 
+// per-channel constants of a lane quarter live in LDS ([4*Q] floats each) and are re-read when needed instead of
+// occupying Q registers each for the whole kernel
+__device__ __forceinline__ float lds_chan(const float* __restrict__ tab, int Q, int kc, int j) { return tab[Q * kc + j]; }

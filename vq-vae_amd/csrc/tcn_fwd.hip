@@ -7,7 +7,12 @@
 #include "tcn_common.hpp"
 #include "frl_host.hpp"
 
-template <typename T, int NFI, int MBO>
+// TP = number of time steps cached in registers per pixel (0 = fetch taps from memory on demand, any T)
+template <typename T, int NFI, int TP> constexpr bool tcn_tp_ok() {
+  return TP == 0 || (NFI * DT<T>::FE * 4 == 64 && TP * NFI * (int)sizeof(typename DT<T>::frag_t) / 4 <= 80);
+}
+
+template <typename T, int NFI, int MBO, int TP, int DIL>
 __global__ __launch_bounds__(256) void tcn_block_fwd_kernel(const T* __restrict__ X, const typename DT<T>::frag_t* __restrict__ Wpk,
                                                             const float* __restrict__ bc,
                                                             const float* __restrict__ gn_w, const float* __restrict__ gn_b,
@@ -20,12 +25,23 @@ __global__ __launch_bounds__(256) void tcn_block_fwd_kernel(const T* __restrict_
   extern __shared__ __attribute__((aligned(16))) char smem[];
   frag_t* wl_conv = reinterpret_cast<frag_t*>(smem);                // [3][MBO][NFI][64]
   frag_t* wl_gate = wl_conv + 3 * MBO * NFI * 64;                   // [MBO][NFO][64]
-  frag_t* wl_proj = wl_gate + MBO * NFO * 64;                       // [MBO][NFI][64] (only if Wp)
+  frag_t* wl_proj = wl_gate + MBO * NFO * 64;                       // [MBO][NFI][64] (only if has_proj)
+  float* tab = reinterpret_cast<float*>(wl_proj + (has_proj ? MBO * NFI * 64 : 0));   // gw | gb | gbias | pb, each [4*Q]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, kc = lane >> 4;
   copy_frags_lds<T>(wl_conv, Wpk, (3 * MBO * NFI + MBO * NFO + (has_proj ? MBO * NFI : 0)) * 64, tid, 256);
+  for (int i = tid; i < 4 * Q; i += 256) {
+    const bool ok = i < a.Cout;
+    tab[i] = ok ? gn_w[i] : 0.f;
+    tab[4 * Q + i] = ok ? gn_b[i] : 0.f;
+    tab[8 * Q + i] = ok ? bg[i] : 0.f;
+    tab[12 * Q + i] = (ok && has_proj) ? bp[i] : 0.f;
+  }
   __syncthreads();
-  const float* Wp = has_proj ? bp : nullptr;   // non-null marker for the projection branches below
+  const float* tgw = tab + Q * kc;
+  const float* tgb = tab + 4 * Q + Q * kc;
+  const float* tbg = tab + 8 * Q + Q * kc;
+  const float* tpb = tab + 12 * Q + Q * kc;
 
   const bool fast_in = (a.Cin == 4 * NFI * FE), fast_out = (a.Cout == 4 * Q);
   const int64_t ntile = (a.npix + 15) >> 4;
@@ -35,60 +51,50 @@ __global__ __launch_bounds__(256) void tcn_block_fwd_kernel(const T* __restrict_
     if (!valid) pidx = a.npix - 1;
     const int64_t b = pidx / a.HW, hw = pidx % a.HW;
     const int64_t row0 = b * a.Tn * a.HW + hw;
-    float mean[Q], rstd[Q];
-    tcn_stats<T, NFI, MBO>(mean, rstd, X, row0, a, kc, fast_in, wl_conv, bc, lane);
-    float cb[Q], gw[Q], gb[Q], gbias[Q], pb[Q];
+    XCache<T, NFI, TP> xc;
+    xcache_load<T, NFI, TP>(xc, X, row0, a, a.Cin, kc, fast_in);
+    float A[Q], Bc[Q];
+    tcn_stats<T, NFI, MBO, TP>(A, Bc, xc, X, row0, a, kc, fast_in, wl_conv, bc, lane);
 #pragma unroll
-    for (int j = 0; j < Q; ++j) {
-      const int c = Q * kc + j;
-      const bool ok = c < a.Cout;
-      cb[j] = ok ? bc[c] : 0.f;
-      gw[j] = ok ? gn_w[c] : 0.f;
-      gb[j] = ok ? gn_b[c] : 0.f;
-      gbias[j] = ok ? bg[c] : 0.f;
-      pb[j] = (ok && Wp != nullptr) ? bp[c] : 0.f;
-    }
+    for (int j = 0; j < Q; ++j) { const float gw = tgw[j]; Bc[j] = fmaf(Bc[j], gw, tgb[j]); A[j] *= gw; }   // n = acc*A + Bc
     for (int t = 0; t < a.Tn; ++t) {
       f32x4 acc[MBO];
 #pragma unroll
       for (int m = 0; m < MBO; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      tconv_at<T, NFI, MBO>(acc, X, row0, a, t, a.Cin, kc, fast_in, wl_conv, lane);
+      tconv_at<T, NFI, MBO, TP>(acc, xc, X, row0, a, t, a.Cin, kc, fast_in, wl_conv, lane);
       float n[Q];
 #pragma unroll
-      for (int j = 0; j < Q; ++j) n[j] = fmaf((acc[j >> 2][j & 3] + cb[j] - mean[j]) * rstd[j], gw[j], gb[j]);
+      for (int j = 0; j < Q; ++j) n[j] = fmaf(acc[j >> 2][j & 3], A[j], Bc[j]);
       LQTile<T, NFO> nt;
       acc_to_tile<T, MBO>(nt, n);
       f32x4 gacc[MBO];
 #pragma unroll
       for (int m = 0; m < MBO; ++m) gacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
       pw_at<T, NFO, MBO>(gacc, nt, wl_gate, lane);
-      // residual
       LQTile<T, NFI> xt;
-      lq_load<T, NFI>(xt, X, row0 + (int64_t)t * a.HW, a.Cin, kc, fast_in);
-      float res[Q];
-      if (Wp != nullptr) {
+      xcache_get<T, NFI, TP>(xt, xc, X, row0, a, t, a.Cin, kc, fast_in);
+      float y[Q];
+      if (has_proj) {
         f32x4 pacc[MBO];
 #pragma unroll
         for (int m = 0; m < MBO; ++m) pacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
         pw_at<T, NFI, MBO>(pacc, xt, wl_proj, lane);
 #pragma unroll
-        for (int j = 0; j < Q; ++j) res[j] = pacc[j >> 2][j & 3] + pb[j];
+        for (int j = 0; j < Q; ++j) y[j] = pacc[j >> 2][j & 3] + tpb[j];
       } else {
-        // identity: Cin == Cout, same padded width -> x tile is already the lane-quarter image
-        if constexpr (NFI * FE == Q) {
+        if constexpr (NFI * FE == Q) {      // identity residual: x tile is already the lane-quarter image
 #pragma unroll
-          for (int j = 0; j < Q; ++j) res[j] = lq_get<T, NFI>(xt, j / FE, j % FE);
+          for (int j = 0; j < Q; ++j) y[j] = lq_get<T, NFI>(xt, j / FE, j % FE);
         } else {
 #pragma unroll
-          for (int j = 0; j < Q; ++j) res[j] = 0.f;
+          for (int j = 0; j < Q; ++j) y[j] = 0.f;
         }
       }
-      float y[Q];
 #pragma unroll
       for (int j = 0; j < Q; ++j) {
-        const float g = 1.f / (1.f + expf(-(gacc[j >> 2][j & 3] + gbias[j])));
+        const float g = 1.f / (1.f + expf(-(gacc[j >> 2][j & 3] + tbg[j])));
         const float o = n[j] > 0.f ? n[j] : 0.f;
-        y[j] = g * o + (1.f - g) * res[j];
+        y[j] = g * o + (1.f - g) * y[j];
       }
       if (valid) {
         LQTile<T, NFO> yt;
@@ -100,9 +106,8 @@ __global__ __launch_bounds__(256) void tcn_block_fwd_kernel(const T* __restrict_
 }
 
 // Generic 3-tap temporal convolution with optional extra pointwise term:
-//   Y[t] = sum_k W_k X[t + (k-1) dil]  (+ R[t] if add_r)  (+ Wp R2[t])
-// Weff_k[o][i] = W[o * so + i * si + (rev ? 2 - k : k)]; used as conv^T in the TCN backward.
-template <typename T, int NFI, int MBO, int NFP>
+//   Y[t] = sum_k W_k X[t + (k-1) dil]  (+ R[t])  (+ Wp R2[t]);  used as conv^T (+ residual path) in the TCN backward.
+template <typename T, int NFI, int MBO, int NFP, int TP, int DIL>
 __global__ __launch_bounds__(256) void tconv3_kernel(const T* __restrict__ X, const typename DT<T>::frag_t* __restrict__ Wpk,
                                                      const T* __restrict__ R, const T* __restrict__ R2, int has_p,
                                                      int Cp, T* __restrict__ Y, TcnArgs a) {
@@ -116,7 +121,6 @@ __global__ __launch_bounds__(256) void tconv3_kernel(const T* __restrict__ X, co
   const int px = lane & 15, kc = lane >> 4;
   copy_frags_lds<T>(wl_conv, Wpk, (3 * MBO * NFI + (has_p ? MBO * NFP : 0)) * 64, tid, 256);
   __syncthreads();
-  const bool Wp = has_p != 0;
   const bool fast_in = (a.Cin == 4 * NFI * FE), fast_out = (a.Cout == 4 * Q), fast_p = (Cp == 4 * NFP * FE);
   const int64_t ntile = (a.npix + 15) >> 4;
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
@@ -125,12 +129,14 @@ __global__ __launch_bounds__(256) void tconv3_kernel(const T* __restrict__ X, co
     if (!valid) pidx = a.npix - 1;
     const int64_t b = pidx / a.HW, hw = pidx % a.HW;
     const int64_t row0 = b * a.Tn * a.HW + hw;
+    XCache<T, NFI, TP> xc;
+    xcache_load<T, NFI, TP>(xc, X, row0, a, a.Cin, kc, fast_in);
     for (int t = 0; t < a.Tn; ++t) {
       f32x4 acc[MBO];
 #pragma unroll
       for (int m = 0; m < MBO; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      tconv_at<T, NFI, MBO>(acc, X, row0, a, t, a.Cin, kc, fast_in, wl_conv, lane);
-      if (Wp) {
+      tconv_at<T, NFI, MBO, TP>(acc, xc, X, row0, a, t, a.Cin, kc, fast_in, wl_conv, lane);
+      if (has_p) {
         LQTile<T, NFP> rt;
         lq_load<T, NFP>(rt, R2, row0 + (int64_t)t * a.HW, Cp, kc, fast_p);
         pw_at<T, NFP, MBO>(acc, rt, wl_p, lane);
@@ -155,9 +161,23 @@ __global__ __launch_bounds__(256) void tconv3_kernel(const T* __restrict__ X, co
 
 static unsigned tcn_grid(int64_t npix) {
   int64_t g = ((npix + 15) / 16 + 3) / 4;
-  if (g > 2048) g = 2048;
+  if (g > 1024) g = 1024;
   if (g < 1) g = 1;
   return (unsigned)g;
+}
+
+template <typename T, int NFI, int MBO, int TP, int DIL>
+static int launch_tcn_fwd_tp(const void* x, const float* bc, const float* gw, const float* gb, const float* bg, const float* wp,
+                             const float* bp, void* y, const TcnArgs& a, void* ws, size_t lds, hipStream_t st) {
+  typedef typename DT<T>::frag_t frag_t;
+  if constexpr (tcn_tp_ok<T, NFI, TP>()) {
+    auto kern = tcn_block_fwd_kernel<T, NFI, MBO, TP, DIL>;
+    if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FRL_LAUNCH(kern, dim3(tcn_grid(a.npix)), dim3(256), lds, st, (const T*)x, (const frag_t*)ws, bc, gw, gb, bg, wp ? 1 : 0, bp, (T*)y, a);
+    return frl_check_launch("tcn_block_fwd");
+  } else {
+    return launch_tcn_fwd_tp<T, NFI, MBO, 0, 0>(x, bc, gw, gb, bg, wp, bp, y, a, ws, lds, st);
+  }
 }
 
 template <typename T, int NFI, int MBO>
@@ -166,15 +186,29 @@ static int launch_tcn_fwd(const void* x, const float* wc, const float* bc, const
                           hipStream_t st) {
   typedef typename DT<T>::frag_t frag_t;
   constexpr int NFO = 4 * MBO / DT<T>::FE;
-  const size_t lds = (size_t)(3 * MBO * NFI + MBO * NFO + (wp ? MBO * NFI : 0)) * 64 * sizeof(frag_t);
+  const size_t wbytes = (size_t)(3 * MBO * NFI + MBO * NFO + (wp ? MBO * NFI : 0)) * 64 * sizeof(frag_t);
+  const size_t lds = wbytes + (size_t)16 * 4 * MBO * sizeof(float);
   if (lds > 160 * 1024) return frl_fail(-3, "tcn_block_fwd: weights exceed LDS");
-  if (ws == nullptr || ws_bytes < lds) return frl_fail(-4, "tcn_block_fwd: workspace too small for the packed weights");
+  if (ws == nullptr || ws_bytes < wbytes) return frl_fail(-4, "tcn_block_fwd: workspace too small for the packed weights");
   FRL_LAUNCH((tcn_pack_kernel<T, NFI, MBO, NFI>), dim3(32), dim3(256), 0, st, (frag_t*)ws, 0, wc, (int64_t)a.Cin * 3, (int64_t)3, 0, wg, wp,
              (int64_t)a.Cin, (int64_t)1, a.Cin, a.Cin, a.Cout);
-  auto kern = tcn_block_fwd_kernel<T, NFI, MBO>;
-  if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  FRL_LAUNCH(kern, dim3(tcn_grid(a.npix)), dim3(256), lds, st, (const T*)x, (const frag_t*)ws, bc, gw, gb, bg, wp ? 1 : 0, bp, (T*)y, a);
-  return frl_check_launch("tcn_block_fwd");
+  if (a.Tn <= 5) return launch_tcn_fwd_tp<T, NFI, MBO, 5, 0>(x, bc, gw, gb, bg, wp, bp, y, a, ws, lds, st);
+  return launch_tcn_fwd_tp<T, NFI, MBO, 0, 0>(x, bc, gw, gb, bg, wp, bp, y, a, ws, lds, st);
+}
+
+template <typename T, int NFI, int MBO, int NFP, int TP, int DIL>
+static int launch_tconv3_tp(const void* x, const void* r, const void* r2, const float* wp, int Cp, void* y, const TcnArgs& a, void* ws,
+                            size_t lds, hipStream_t st) {
+  typedef typename DT<T>::frag_t frag_t;
+  if constexpr (tcn_tp_ok<T, NFI, TP>()) {
+    auto kern = tconv3_kernel<T, NFI, MBO, NFP, TP, DIL>;
+    if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FRL_LAUNCH(kern, dim3(tcn_grid(a.npix)), dim3(256), lds, st, (const T*)x, (const frag_t*)ws, (const T*)r, (const T*)r2, wp ? 1 : 0,
+               Cp, (T*)y, a);
+    return frl_check_launch("tconv3");
+  } else {
+    return launch_tconv3_tp<T, NFI, MBO, NFP, 0, 0>(x, r, r2, wp, Cp, y, a, ws, lds, st);
+  }
 }
 
 template <typename T, int NFI, int MBO, int NFP>
@@ -187,11 +221,8 @@ static int launch_tconv3(const void* x, const float* w, int64_t so, int64_t si, 
   if (ws == nullptr || ws_bytes < lds) return frl_fail(-4, "tconv3: workspace too small for the packed weights");
   FRL_LAUNCH((tcn_pack_kernel<T, NFI, MBO, NFP>), dim3(32), dim3(256), 0, st, (frag_t*)ws, 2, w, so, si, rev, (const float*)nullptr, wp,
              pso, psi, Cp, a.Cin, a.Cout);
-  auto kern = tconv3_kernel<T, NFI, MBO, NFP>;
-  if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  FRL_LAUNCH(kern, dim3(tcn_grid(a.npix)), dim3(256), lds, st, (const T*)x, (const frag_t*)ws, (const T*)r, (const T*)r2, wp ? 1 : 0,
-             Cp, (T*)y, a);
-  return frl_check_launch("tconv3");
+  if (a.Tn <= 5) return launch_tconv3_tp<T, NFI, MBO, NFP, 5, 0>(x, r, r2, wp, Cp, y, a, ws, lds, st);
+  return launch_tconv3_tp<T, NFI, MBO, NFP, 0, 0>(x, r, r2, wp, Cp, y, a, ws, lds, st);
 }
 
 // padded-width class: f32 -> {16,32,64,128} ; bf16 -> {32,64,128}

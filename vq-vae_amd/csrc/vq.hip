@@ -230,9 +230,12 @@ __global__ __launch_bounds__(256) void vq_fixup_kernel(const T* __restrict__ Z, 
                                                        const int32_t* __restrict__ amb_list, VqHeader* __restrict__ hdr,
                                                        int32_t* __restrict__ idx_out, T* __restrict__ zq_out,
                                                        int32_t* __restrict__ counts_fix) {
+  // per wave: z row [d] + a 64-code tile of the (rounded) codebook with pitch d+1 (conflict-free column reads)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* zrow = reinterpret_cast<float*>(smem) + (size_t)wave * d;
+  const int pitch = d + 1;
+  float* zrow = reinterpret_cast<float*>(smem) + (size_t)wave * (d + 64 * pitch);
+  float* et = zrow + d;
   const int namb = hdr->namb;
   const int nwaves = gridDim.x * 4;
   const float slack = 2.f * (float)(d + 8) * 1.1920929e-7f;
@@ -240,27 +243,32 @@ __global__ __launch_bounds__(256) void vq_fixup_kernel(const T* __restrict__ Z, 
     const int64_t n = amb_list[it];
     __builtin_amdgcn_wave_barrier();
     for (int j = lane; j < d; j += 64) zrow[j] = to_f32(Z[n * (int64_t)d + j]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    float m32 = 3.0e38f;
-    for (int k = lane; k < K; k += 64) {
-      const float* er = E + (int64_t)k * d;
-      float s = 0.f;
-      for (int j = 0; j < d; ++j) { const float df = zrow[j] - to_f32(from_f32<T>(er[j])); s = fmaf(df, df, s); }
-      m32 = fminf(m32, s);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m32 = fminf(m32, __shfl_xor(m32, off, 64));
-    const float bound = m32 * (1.f + slack) + 1e-30f;
+    float m32 = 3.0e38f;                       // running f32 minimum (wave-uniform)
     double best = 1.0e300;
     int bestk = 0x7fffffff;
-    for (int k = lane; k < K; k += 64) {
-      const float* er = E + (int64_t)k * d;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      __builtin_amdgcn_wave_barrier();
+      // cooperative, coalesced load of codes k0..k0+63 (row-major in memory) into the padded LDS tile
+      const int nel = 64 * d;
+      for (int i = lane; i < nel; i += 64) {
+        const int kk = i / d, j = i - kk * d;
+        et[kk * pitch + j] = (k0 + kk < K) ? to_f32(from_f32<T>(E[(int64_t)(k0 + kk) * d + j])) : 0.f;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int k = k0 + lane;
+      const float* er = et + lane * pitch;
       float s = 0.f;
-      for (int j = 0; j < d; ++j) { const float df = zrow[j] - to_f32(from_f32<T>(er[j])); s = fmaf(df, df, s); }
-      if (s <= bound) {
+      for (int j = 0; j < d; ++j) { const float df = zrow[j] - er[j]; s = fmaf(df, df, s); }
+      if (k >= K) s = 3.0e38f;
+      float cm = s;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) cm = fminf(cm, __shfl_xor(cm, off, 64));
+      m32 = fminf(m32, cm);
+      // every code within the f32 rounding bound of the (still decreasing) running minimum is evaluated exactly
+      if (s <= m32 * (1.f + slack) + 1e-30f) {
         double sd = 0.0;
-        for (int j = 0; j < d; ++j) { const double df = (double)zrow[j] - (double)to_f32(from_f32<T>(er[j])); sd += df * df; }
+        for (int j = 0; j < d; ++j) { const double df = (double)zrow[j] - (double)er[j]; sd += df * df; }
         if (sd < best) { best = sd; bestk = k; }
       }
     }
@@ -273,6 +281,75 @@ __global__ __launch_bounds__(256) void vq_fixup_kernel(const T* __restrict__ Z, 
     float sq = 0.f;
     for (int j = lane; j < d; j += 64) {
       const float ev = to_f32(from_f32<T>(E[(int64_t)bestk * d + j]));
+      zq_out[n * (int64_t)d + j] = from_f32<T>(ev);
+      const float df = zrow[j] - ev;
+      sq = fmaf(df, df, sq);
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) {
+      idx_out[n] = bestk;
+      atomicAdd(&counts_fix[bestk], 1);
+      atomicAdd(&hdr->sq_fix, (double)sq);
+    }
+  }
+}
+
+// Same re-evaluation with the WHOLE (rounded) codebook resident in LDS ([K][d+1] f32, conflict-free column reads): one
+// coalesced fill per workgroup, then each wave walks its share of the flagged rows.  Used when K*(d+1)*4 fits in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void vq_fixup_lds_kernel(const T* __restrict__ Z, const float* __restrict__ E, int K, int d,
+                                                           const int32_t* __restrict__ amb_list, VqHeader* __restrict__ hdr,
+                                                           int32_t* __restrict__ idx_out, T* __restrict__ zq_out,
+                                                           int32_t* __restrict__ counts_fix) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pitch = d + 1;
+  float* et = reinterpret_cast<float*>(smem);               // [K][pitch]
+  float* zrow = et + (size_t)K * pitch + (size_t)wave * d;  // [4][d]
+  const int namb = hdr->namb;
+  if ((int)blockIdx.x * 4 >= namb) return;                  // whole workgroup has no rows: skip the fill
+  for (int i = tid; i < K * d; i += 256) {
+    const int kk = i / d, j = i - kk * d;
+    et[kk * pitch + j] = to_f32(from_f32<T>(E[i]));
+  }
+  __syncthreads();
+  const int nwaves = gridDim.x * 4;
+  const float slack = 2.f * (float)(d + 8) * 1.1920929e-7f;
+  for (int it = blockIdx.x * 4 + wave; it < namb; it += nwaves) {
+    const int64_t n = amb_list[it];
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < d; j += 64) zrow[j] = to_f32(Z[n * (int64_t)d + j]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float m32 = 3.0e38f;
+    double best = 1.0e300;
+    int bestk = 0x7fffffff;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      const int k = k0 + lane;
+      const float* er = et + (k < K ? k : K - 1) * pitch;
+      float s = 0.f;
+      for (int j = 0; j < d; ++j) { const float df = zrow[j] - er[j]; s = fmaf(df, df, s); }
+      if (k >= K) s = 3.0e38f;
+      float cm = s;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) cm = fminf(cm, __shfl_xor(cm, off, 64));
+      m32 = fminf(m32, cm);
+      if (s <= m32 * (1.f + slack) + 1e-30f) {
+        double sd = 0.0;
+        for (int j = 0; j < d; ++j) { const double df = (double)zrow[j] - (double)er[j]; sd += df * df; }
+        if (sd < best) { best = sd; bestk = k; }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_xor(best, off, 64);
+      const int ok = __shfl_xor(bestk, off, 64);
+      if (ob < best || (ob == best && ok < bestk)) { best = ob; bestk = ok; }
+    }
+    float sq = 0.f;
+    const float* eb = et + bestk * pitch;
+    for (int j = lane; j < d; j += 64) {
+      const float ev = eb[j];
       zq_out[n * (int64_t)d + j] = from_f32<T>(ev);
       const float df = zrow[j] - ev;
       sq = fmaf(df, df, sq);
@@ -486,8 +563,21 @@ static int launch_vq(const void* z, const float* E, int64_t N, int K, int d, int
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   FRL_LAUNCH(kern, dim3(L.grid), dim3(256), lds, st, (const T*)z, E, en, hdr, N, K, d, Kc, idx, (T*)zq,
              (float*)(ws + L.partial), (int32_t*)(ws + L.hist), hdr, (int32_t*)(ws + L.amb));
-  FRL_LAUNCH((vq_fixup_kernel<T>), dim3(VQ_FIX_WAVES / 4), dim3(256), (size_t)4 * d * sizeof(float), st, (const T*)z, E, K, d,
-             (const int32_t*)(ws + L.amb), hdr, idx, (T*)zq, (int32_t*)(ws + L.counts_fix));
+  const size_t fix_lds = (size_t)4 * (d + 64 * (d + 1)) * sizeof(float);
+  {
+    auto fk = vq_fixup_kernel<T>;
+    if (fix_lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fix_lds));
+  }
+  const size_t res_lds = ((size_t)K * (d + 1) + 4 * (size_t)d) * sizeof(float);
+  if (res_lds <= 150 * 1024) {
+    auto fk = vq_fixup_lds_kernel<T>;
+    if (res_lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds));
+    FRL_LAUNCH(fk, dim3(128), dim3(256), res_lds, st, (const T*)z, E, K, d, (const int32_t*)(ws + L.amb), hdr, idx, (T*)zq,
+               (int32_t*)(ws + L.counts_fix));
+  } else {
+    FRL_LAUNCH((vq_fixup_kernel<T>), dim3(VQ_FIX_WAVES / 4), dim3(256), fix_lds, st, (const T*)z, E, K, d,
+               (const int32_t*)(ws + L.amb), hdr, idx, (T*)zq, (int32_t*)(ws + L.counts_fix));
+  }
   launch_slab_reduce<int32_t, HistEpi>((const int32_t*)(ws + L.hist), L.grid, K, HistEpi{(const int32_t*)(ws + L.counts_fix), counts}, st);
   FRL_LAUNCH(vq_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)(ws + L.partial), L.grid * 4, (const VqHeader*)hdr,
              (const int32_t*)counts, K, N, stats);
@@ -514,7 +604,7 @@ size_t frl_vq_workspace_bytes(int64_t N, int K, int d) {
 int frl_vq_assign_fwd(const void* z, const float* E, int64_t N, int K, int d, int32_t* idx_out, void* zq_out,
                       float* stats_out, int32_t* counts_out, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (N <= 0 || K <= 0 || d <= 0) return frl_fail(-2, "vq_assign: empty input");
-  if (d > 256) return frl_fail(-2, "vq_assign: d > 256 unsupported");
+  if (d > 128) return frl_fail(-2, "vq_assign: d > 128 unsupported");
   if (ws_bytes < frl_vq_workspace_bytes(N, K, d)) return frl_fail(-4, "vq_assign: workspace too small");
   char* w = (char*)ws;
   // partial_fix sits right after partial so that finalize sums one contiguous array
