@@ -59,7 +59,7 @@ def cpu_baseline(args):
     """Oracle train step on the host cores (rank 0, N=1): bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import frl_oracle as O
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)      # the box's CPU share for one GPU; more threads only thrash on these small ops
     torch.set_num_threads(cores)
     bs = 8
     g = torch.Generator().manual_seed(0)
@@ -117,16 +117,22 @@ def main():
         trainer.step(stream.next())
     timing = (not args.no_kernel_timing) and rank == 0
     barrier()
-    if timing:
-        ops.set_timing(True)
     t0 = time.perf_counter()
     last = None
-    for _ in range(args.steps):
+    for _ in range(args.steps):                       # timed region: exactly K steps, no instrumentation
         last = trainer.step(stream.next())
     barrier()
     dt = time.perf_counter() - t0
-    ksum = ops.timing_summary() if timing else {}
-    ops.set_timing(False)
+    ksum, ksteps = {}, 0
+    if timing:                                        # separate instrumented steps: HIP events around every C-ABI call
+        ksteps = max(2, min(5, args.steps))
+        ops.set_timing(True)
+        for _ in range(ksteps):
+            trainer.step(stream.next())
+        ksum = ops.timing_summary()
+        ops.set_timing(False)
+    if world > 1:
+        barrier()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -145,28 +151,31 @@ def main():
                                f"fwd+bwd+clip+AdamW), {args.batch} tiles/GPU of {args.time}x{args.size}x{args.size}x{args.features}, "
                                f"K={args.codebook}, d={args.emb_dim}, dropout 0.0",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}", "finite_check": not args.no_finite_check,
-                   "loss": round(float(last["loss"]), 5), "perplexity": round(float(last["perplexity"]), 2)},
+                   "loss": round(float(last["loss"].detach()), 5), "perplexity": round(float(last["perplexity"]), 2)},
     }
     if ksum:
+        args.steps_timed, args.steps = args.steps, ksteps           # per-step normalisation of the instrumented steps
         n = args.batch * args.size * args.size                      # vectors / pixels per step
         s = 2 if args.dtype == "bf16" else 4
-        fam = {k: {"calls_per_step": c / args.steps, "ms_per_step": round(ms / args.steps, 4)} for k, (c, ms) in ksum.items()}
-        out["kernels"] = fam
+        out["kernels"] = {k: {"calls_per_step": c / args.steps, "ms_per_step": round(ms / args.steps, 4)} for k, (c, ms) in ksum.items()}
         # --- VQ assign: HBM roofline, algorithmic bytes = 2*d*s + 4 per vector (+ K*d*4 codebook once)
         vq_ms = ksum["vq_assign"][1] / ksum["vq_assign"][0]
         vq_bytes = n * (2 * args.emb_dim * s + 4) + args.codebook * args.emb_dim * 4
         out["vq_hbm"] = {"GB/s": round(vq_bytes / vq_ms / 1e6, 1), "frac": round(vq_bytes / vq_ms / 1e6 / HBM_PEAK_GBS, 4),
-                         "ms": round(vq_ms, 4), "note": "span = prep + assign + float64 fix-up + finalize launches"}
-        # --- conv MFMA: all dense contractions of the step vs time spent in conv/tcn kernels
-        conv_keys = [k for k in ksum if k.startswith(("conv", "tcn"))]
-        conv_ms = sum(ksum[k][1] for k in conv_keys if k != "conv1x1_bwd_weight" or True) / args.steps
-        # tcn_block_bwd's span already contains its nested wgrad calls; subtract the nested pointwise wgrad time once
+                         "ms": round(vq_ms, 4), "bytes": vq_bytes,
+                         "note": "event span of frl_vq_assign_fwd = prep + assign + float64 fix-up + reductions; per-kernel split in profiles/"}
+        # --- conv MFMA: algorithmic dense FLOPs of the step (3 x forward) over the event time of every conv / TCN op
+        conv_keys = [k for k in ksum if k.startswith(("conv", "tcn")) and k != "tcn_block_bwd.main"]
+        conv_ms = sum(ksum[k][1] for k in conv_keys) / args.steps
         flops = 3 * conv_flops_per_tile(args.time, args.size, args.features, args.emb_dim, model.z_phase_dim) * args.batch
         out["conv_mfma"] = {"TFLOP/s": round(flops / conv_ms / 1e9, 1), "frac": round(flops / conv_ms / 1e9 / MFMA_BF16_PEAK_TF, 4),
-                            "ms_per_step": round(conv_ms, 3), "note": "algorithmic 3x fwd dense FLOPs / event time of conv+tcn ops"}
-        # --- dominant op -> headline roofline object
-        dom = max((k for k in ksum if k != "conv1x1_bwd_weight"), key=lambda k: ksum[k][1])
+                            "ms_per_step": round(conv_ms, 3), "GFLOP_per_step": round(flops / 1e9, 1),
+                            "note": "algorithmic 3x-forward dense FLOPs / HIP-event time of all conv + TCN ops"}
+        # --- dominant kernel -> headline roofline object
+        cands = [k for k in ksum if k != "tcn_block_bwd"]
+        dom = max(cands, key=lambda k: ksum[k][1])
         out["roofline"] = roofline_for(dom, ksum, args, model, n, s)
+        args.steps = args.steps_timed
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(out), flush=True)
@@ -174,26 +183,45 @@ def main():
         dist.destroy_process_group()
 
 
+def pmc_traffic(name):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r*_pmc.json), or None."""
+    key = {"tcn_block_bwd.main": "tcn_block_bwd_kernel", "tcn_block_fwd": "tcn_block_fwd_kernel", "vq_assign": "vq_assign_kernel"}.get(name)
+    try:
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]
+        for k, v in json.load(open(f))["kernels"].items():
+            if key and key in k:
+                return v["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def roofline_for(name, ksum, args, model, n, s):
-    """Roofline entry for the op with the largest share of the step; per-launch algorithmic work / average launch time."""
+    """Roofline entry for the kernel with the largest share of the step: per-launch algorithmic work / average launch time
+    (HIP events recorded on the launch stream around the C-ABI call)."""
     calls, ms = ksum[name]
     avg = ms / calls
-    T, F, d, zp = args.time, args.features, args.emb_dim, model.z_phase_dim
+    T, d = args.time, args.emb_dim
+    base = {"kernel": name, "traffic": pmc_traffic(name), "avg_ms": round(avg, 4), "launches_per_step": calls / args.steps}
     if name.startswith("tcn_block"):
         rows = n * T
+        # valid temporal taps averaged over the three dilations (1, 2, 4) at this T
+        taps = sum(sum(1 for t in range(T) for k in (-1, 0, 1) if 0 <= t + k * dl < T) for dl in (1, 2, 4)) / (3.0 * T)
         if name == "tcn_block_fwd":
-            flops = rows * (2 * 64 * 64 * 3 * 2 + 2 * 64 * 64)   # conv evaluated twice (stats + apply) + gate GEMM
-            algo = rows * (2 * 64 * 3 + 2 * 64 * 64 // 64) and rows * (2 * (64 * 64 * 3 + 64 * 64))
+            algo = rows * 2 * 64 * 64 * (taps + 1)                  # conv + gate GEMM
         else:
-            algo = rows * (2 * (64 * 64 * 3 + 64 * 64)) * 2       # backward of conv + gate: data + weight gradients
-        return {"kernel": name, "bound": "mfma", "achieved": round(algo / avg / 1e9, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-                "frac": round(algo / avg / 1e9 / MFMA_BF16_PEAK_TF, 4), "traffic": None, "avg_ms": round(avg, 4)}
+            algo = rows * 2 * 64 * 64 * (taps + 2)                  # conv recompute + gate + gate^T GEMMs (dx and weight grads are other launches)
+        base.update({"bound": "mfma", "achieved": round(algo / avg / 1e9, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": round(algo / avg / 1e9 / MFMA_BF16_PEAK_TF, 4), "flops_per_launch": algo})
+        return base
     if name == "vq_assign":
         b = n * (2 * d * s + 4) + args.codebook * d * 4
-        return {"kernel": name, "bound": "hbm", "achieved": round(b / avg / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(b / avg / 1e6 / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(avg, 4)}
-    return {"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-            "avg_ms": round(avg, 4)}
+        base.update({"bound": "hbm", "achieved": round(b / avg / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(b / avg / 1e6 / HBM_PEAK_GBS, 4), "bytes_per_launch": b})
+        return base
+    base.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None})
+    return base
 
 
 if __name__ == "__main__":

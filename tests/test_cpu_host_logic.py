@@ -1,0 +1,99 @@
+"""Host-side logic that needs no GPU: dataset / collate contract, config loader, schedules, model construction + state-dict keys."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_forest_dataset_tile_layout_and_collate():
+    from frl_hip.data import ForestDataset, collate_fn
+    ds = ForestDataset(num_tiles=10, time=5, size=32, features=64, seed=1234, channels_first=True, partial_edge=20)
+    assert len(ds) == 10
+    s = ds[0]
+    assert s["tile"].shape == (5, 32, 32, 64) and s["tile"].dtype == np.float32          # (time, y, x, feature)
+    assert s["static"].shape == (64, 32, 32) and s["annual"].shape == (64, 5, 32, 32)     # ForestDatasetV2 group views
+    assert not s["mask"][20:].any() and s["mask"][:20].all() and np.all(s["tile"][:, 20:] == 0)   # zero-padded partial patch
+    assert set(s["metadata"]) == {"spatial_window", "channel_names", "patch_idx"}
+    assert np.array_equal(ds[3]["tile"], ds[3]["tile"])                                   # deterministic per index
+    b = collate_fn([ds[i] for i in range(4)])
+    assert b["tile"].shape == (4, 5, 32, 32, 64) and isinstance(b["metadata"], list) and len(b["metadata"]) == 4
+    with pytest.raises(IndexError):
+        ds[10]
+    assert collate_fn([ds[1]])["tile"].shape[0] == 1
+
+
+def test_vae_v0_yaml_loader():
+    from frl_hip.config import load_vae_config
+    cfg = load_vae_config(os.path.join(ROOT, "configs", "vae_v0.yaml"))
+    assert cfg.batch_size == 256 and cfg.codebook_size == 512 and cfg.emb_dim == 64 and cfg.beta == 0.25
+    assert cfg.optimizer.name == "adamw" and cfg.optimizer.lr == 1e-4 and cfg.optimizer.scheduler["eta_min"] == 1e-6
+    assert cfg.beta_schedule["schedule_type"] == "linear" and cfg.quantizer == "st"
+
+
+def test_vae_v0_reference_key_set_is_accepted(tmp_path):
+    """Every key of the reference's configs/vae_v0.yaml (flat layout) is accepted; zarr-windowing keys land in `extra`."""
+    from frl_hip.config import load_vae_config
+    p = tmp_path / "ref_like.yaml"
+    p.write_text("zarr_path: /x\npatch_size: 256\nbatch_size: 4\nnum_epochs: 200\nbeta: 0.1\nlambda_cat: 1.0\n"
+                 "optimizer:\n  name: adam\n  lr: 1e-4\n  weight_decay: 0.0\n  scheduler:\n    name: cosine\n    T_max_epochs: 150\n    eta_min: 1.0e-6\n"
+                 "beta_schedule:\n  enabled: true\n  schedule_type: linear\n  start_epoch: 0\n  end_epoch: 100\n  start_value: 0.1\n  end_value: 1.0\n"
+                 "debug_window: true\ndebug_window_origin: [2560, 5120]\ndebug_window_size: [1024, 1024]\ndebug_block_dims: [1, 1]\n"
+                 "full_block_dims: [7, 7]\nnum_workers: 0\npin_memory: true\nrun_root: runs\nexperiment_name: vae_v0_debug\nckpt_dir: checkpoints\n")
+    cfg = load_vae_config(str(p))
+    assert cfg.beta == 0.1 and cfg.optimizer.lr == 1e-4 and cfg.extra["full_block_dims"] == [7, 7]
+    from frl_hip.training.schedules import beta_schedule
+    assert beta_schedule(0, cfg.beta_schedule) == 0.1 and beta_schedule(100, cfg.beta_schedule) == 1.0
+    assert abs(beta_schedule(50, cfg.beta_schedule) - 0.55) < 1e-12
+
+
+def test_schedules():
+    from frl_hip.training import schedules as S
+    assert S.cosine_lr(0, 100, 1e-3, 1e-5) == 1e-3 and abs(S.cosine_lr(100, 100, 1e-3, 1e-5) - 1e-5) < 1e-15
+    assert S.warmup_cosine_factor(0, 10, 100, 0.01) == 1e-8 and S.warmup_cosine_factor(5, 10, 100, 0.01) == 0.5
+    assert abs(S.warmup_cosine_factor(100, 10, 100, 0.01) - 0.01) < 1e-12
+
+
+def test_model_api_surface_and_errors():
+    from frl_hip.models import RepresentationModel, VQVAE
+    m = RepresentationModel(64, 64)
+    assert m.VERSION == "4" and m.type_projection is None and m.project_type(torch.ones(2, 3)).shape == (2, 3)
+    for name in ("encoder", "spatial_conv", "phase_tcn", "phase_head", "phase_film"):
+        assert hasattr(m, name)
+    m.set_spatial_min_gate(0.3)
+    m.set_input_dropout_rate(0.0)
+    assert m.spatial_conv.min_gate == 0.3
+    with pytest.raises(ValueError):
+        RepresentationModel(8, 8, z_type_dim=8, type_encoder_channels=(16, 4))
+    with pytest.raises(ValueError):
+        RepresentationModel.from_config({"version": "3"}, 8, 8)
+    cfg = {"version": "4", "latents": {"z_type_dim": 48, "z_phase_dim": 8},
+           "type_encoder": {"channels": [128, 48], "dropout": [0.0, 0.0], "input_dropout": {"schedule": "linear", "start": 0.0, "end": 0.1, "epochs": 20}},
+           "phase_tcn": {"channels": [64, 64, 64], "dilations": [1, 2, 4], "dropout": 0.0}, "type_projection": {"enabled": False}}
+    m2 = RepresentationModel.from_config(cfg, 16, 8)
+    assert m2.z_type_dim == 48 and m2.z_phase_dim == 8 and "encoder.layers.3.weight" in m2.state_dict()
+    v = VQVAE(in_features=64, codebook_size=512, emb_dim=64)
+    names = dict(v.named_parameters())
+    assert "quant.codebook" in names and names["quant.codebook"].shape == (512, 64)
+    assert v.quant.codebook_size == 512 and v.quant.emb_dim == 64
+    v.attach_codebook_manager(object())
+    with pytest.raises(Exception):       # CPU tensors are refused: HIP only
+        v.forward_tiles(torch.zeros(1, 5, 32, 32, 64))
+
+
+def test_checkpoint_round_trip_cpu(tmp_path):
+    from frl_hip.models import RepresentationModel
+    cfg = {"version": "4", "latents": {"z_type_dim": 8, "z_phase_dim": 4}, "type_encoder": {"channels": [16, 8], "dropout": 0.0, "num_groups": 4},
+           "spatial_conv": {"gate_hidden": 8}, "phase_tcn": {"channels": [8, 8, 8], "dropout": 0.0, "num_groups": 4}}
+    m = RepresentationModel.from_config(cfg, 8, 8)
+    p = tmp_path / "encoder_last.pt"
+    torch.save({"model_version": "4", "model_config": cfg, "type_in_channels": 8, "phase_in_channels": 8,
+                "model_state_dict": m.state_dict(), "epoch": 3}, p)
+    m2 = RepresentationModel.from_checkpoint(p, device="cpu")
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    assert not any(q.requires_grad for q in m2.parameters())
+    torch.save({"model_version": "3"}, p)
+    with pytest.raises(RuntimeError):
+        RepresentationModel.from_checkpoint(p, device="cpu")

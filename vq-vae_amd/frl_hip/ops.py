@@ -32,6 +32,25 @@ def timing_summary():
     return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in _TIMING["events"].items()}
 
 
+class span:
+    """with ops.span("name"): ...  -- HIP-event timing of a sub-range (used for single-kernel roofline numbers)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _TIMING["on"]:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if _TIMING["on"]:
+            self.e1.record()
+            _TIMING["events"].setdefault(self.name, []).append((self.e0, self.e1))
+        return False
+
+
 def _timed(name):
     def deco(fn):
         def wrapper(*a, **kw):
@@ -121,8 +140,7 @@ def conv1x1_bwd_data(dy: torch.Tensor, w: torch.Tensor, y: Optional[torch.Tensor
     return dx
 
 
-@_timed("conv1x1_bwd_weight")
-def conv1x1_bwd_weight(dy: torch.Tensor, x: torch.Tensor, y: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+def _conv1x1_bwd_weight_impl(dy: torch.Tensor, x: torch.Tensor, y: Optional[torch.Tensor] = None, act: int = ACT_NONE,
                        want_bias: bool = True, scalar_frags: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     cout, cin = dy.shape[-1], x.shape[-1]
     _chk_rows(dy, cout, "bwd_weight.dy")
@@ -137,6 +155,9 @@ def conv1x1_bwd_weight(dy: torch.Tensor, x: torch.Tensor, y: Optional[torch.Tens
                                       _dt(dy), _p(ws), ws.numel(), 1 if scalar_frags else 0, _stream()),
           "frl_conv_tap_bwd_weight")
     return dw, db
+
+
+conv1x1_bwd_weight = _timed("conv1x1_bwd_weight")(_conv1x1_bwd_weight_impl)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -415,9 +436,10 @@ def tcn_block_bwd(x, dy, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, pro
     dbet = torch.empty(cout, dtype=torch.float32, device=dev)
     gate_w2 = gate_w.reshape(cout, cout)
     ws = workspace(lib.frl_tcn_block_bwd_workspace_bytes(npix, cout), dev)
-    check(lib.frl_tcn_block_bwd(_p(x), _p(dy), _p(conv_w), _p(conv_b), _p(gn_w), _p(gn_b), _p(gate_w2), _p(gate_b), _p(proj_w),
-                                _p(proj_b), _p(dconv), _p(dgpre), _p(normed), _p(dres), _p(dgam), _p(dbet), npix, hw, t, cin,
-                                cout, dilation, groups, float(eps), _dt(x), _p(ws), ws.numel(), _stream()), "frl_tcn_block_bwd")
+    with span("tcn_block_bwd.main"):
+        check(lib.frl_tcn_block_bwd(_p(x), _p(dy), _p(conv_w), _p(conv_b), _p(gn_w), _p(gn_b), _p(gate_w2), _p(gate_b), _p(proj_w),
+                                    _p(proj_b), _p(dconv), _p(dgpre), _p(normed), _p(dres), _p(dgam), _p(dbet), npix, hw, t, cin,
+                                    cout, dilation, groups, float(eps), _dt(x), _p(ws), ws.numel(), _stream()), "frl_tcn_block_bwd")
     dx = torch.empty_like(x)
     ws1 = workspace(lib.frl_conv_workspace_bytes(max(cin, cout), max(cin, cout), 6), dev)
     check(lib.frl_tcn_block_bwd_data(_p(dconv), _p(dres), _p(conv_w), _p(proj_w), _p(dx), npix, hw, t, cin, cout, dilation,
@@ -430,9 +452,9 @@ def tcn_block_bwd(x, dy, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, pro
         check(lib.frl_conv_tap_bwd_weight(_p(dconv), None, 0, _p(x), ctypes.c_void_p(dw.data_ptr() + 4 * k), cin * 3, 3,
                                           _p(dcb) if k == 1 else None, p, cin, cout, hw, t, (k - 1) * dilation, _dt(x),
                                           _p(ws2), ws2.numel(), 0, _stream()), "frl_conv_tap_bwd_weight")
-    dgw, dgb = conv1x1_bwd_weight(dgpre, normed)
+    dgw, dgb = _conv1x1_bwd_weight_impl(dgpre, normed)
     out = dict(dx=dx, conv_w=dw, conv_b=dcb, gn_w=dgam, gn_b=dbet, gate_w=dgw.reshape(gate_w.shape), gate_b=dgb)
     if proj_w is not None:
-        dpw, dpb = conv1x1_bwd_weight(dres, x)
+        dpw, dpb = _conv1x1_bwd_weight_impl(dres, x)
         out.update(proj_w=dpw.reshape(proj_w.shape), proj_b=dpb)
     return out
