@@ -110,6 +110,15 @@ int frl_tcn_block_bwd_data(const void* dconv, const void* dres, const float* con
                            int64_t npix, int HW, int T, int Cin, int Cout, int dilation, int dtype, void* ws, size_t ws_bytes,
                            frl_stream_t stream);
 
+/* fully fused backward (bf16, Cin = Cout = 64, T <= 5, identity residual): one launch reads x, dy and writes dx and every
+ * parameter gradient of the block; weight gradients are contracted inside the kernel (no HBM side outputs). */
+int frl_tcn_block_bwd_fused_supported(int T, int Cin, int Cout, int G, int has_proj, int dtype);
+size_t frl_tcn_block_bwd_fused_workspace_bytes(int64_t npix);
+int frl_tcn_block_bwd_fused(const void* x, const void* dy, const float* conv_w, const float* conv_b, const float* gn_w,
+                            const float* gn_b, const float* gate_w, const float* gate_b, void* dx, float* d_conv_w,
+                            float* d_conv_b, float* d_gn_w, float* d_gn_b, float* d_gate_w, float* d_gate_b, int64_t npix,
+                            int HW, int T, int dilation, int G, float eps, void* ws, size_t ws_bytes, frl_stream_t stream);
+
 /* ---- FiLM modulation, time mean, add ---------------------------------------------------------------------------
  * z = gamma * h + beta broadcast over T (frl/models/representation.py:369-372); h [B][T][HW][C], gamma [B][HW][C]. */
 int frl_film_modulate_fwd(const void* h, const void* gamma, const void* beta, void* out, int64_t B, int T, int64_t HW,

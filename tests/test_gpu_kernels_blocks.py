@@ -226,3 +226,32 @@ def test_streaming_ops(dtype, atol, wtol):
         assert rel_err(dres.float(), rs.grad) <= atol and rel_err(dgraw.float(), gr_.grad) <= atol
     a, b = q(torch.randn(128, 8, generator=g), dtype), q(torch.randn(128, 8, generator=g), dtype)
     assert rel_err(ops.add(a.to(dtype).to(DEV), b.to(dtype).to(DEV)).float(), a + b) <= atol
+
+
+@pytest.mark.parametrize("B,T,HW,dil", [(1, 5, 1024, 1), (2, 5, 1024, 2), (3, 5, 100, 4), (1, 3, 77, 1), (1, 4, 64, 2)])
+def test_tcn_block_bwd_fused_matches_oracle_and_unfused(B, T, HW, dil):
+    """The fused bf16 backward (one launch: dx + all parameter gradients) vs float64 autograd and vs the unfused kernels."""
+    from frl_hip import ops
+    dtype, cin, cout, G = torch.bfloat16, 64, 64, 8
+    g = torch.Generator().manual_seed(T * HW + dil)
+    p = "b."
+    st = {p + "conv.weight": torch.randn(cout, cin, 3, generator=g) / (3 * cin) ** 0.5, p + "conv.bias": torch.randn(cout, generator=g) * 0.1,
+          p + "norm.weight": torch.rand(cout, generator=g) + 0.5, p + "norm.bias": torch.randn(cout, generator=g) * 0.2,
+          p + "gate.weight": torch.randn(cout, cout, 1, generator=g) / cout ** 0.5, p + "gate.bias": torch.randn(cout, generator=g) * 0.1}
+    ref_st = {k: ((q(v, dtype) if k.endswith(("conv.weight", "gate.weight")) else v.double()).requires_grad_(True)) for k, v in st.items()}
+    x = q(torch.randn(B, T, HW, cin, generator=g), dtype).requires_grad_(True)
+    yr = O.tcn_block_forward(ref_st, x.permute(0, 2, 3, 1).reshape(B * HW, cin, T), dil, G, p)
+    dy = q(torch.randn(B, T, HW, cout, generator=g), dtype)
+    yr.reshape(B, HW, cout, T).permute(0, 3, 1, 2).backward(dy)
+    dev = {k: v.float().to(DEV) for k, v in st.items()}
+    args = (dev[p + "conv.weight"], dev[p + "conv.bias"], dev[p + "norm.weight"], dev[p + "norm.bias"], dev[p + "gate.weight"], dev[p + "gate.bias"], None, None)
+    xd, dyd = x.detach().to(dtype).to(DEV), dy.to(dtype).to(DEV)
+    fused = ops.tcn_block_bwd(xd, dyd, *args, dil, G)
+    unf = ops.tcn_block_bwd(xd, dyd, *args, dil, G, allow_fused=False)
+    names = dict(conv_w="conv.weight", conv_b="conv.bias", gn_w="norm.weight", gn_b="norm.bias", gate_w="gate.weight", gate_b="gate.bias")
+    assert rel_err(fused["dx"].float(), x.grad) <= 0.1
+    assert rel_err(fused["dx"].float(), unf["dx"].float().cpu()) <= 0.05
+    for kk, nm in names.items():
+        ref = ref_st[p + nm].grad
+        assert rel_err(fused[kk].reshape(ref.shape), ref) <= 0.1, kk
+        assert rel_err(fused[kk].reshape(ref.shape), unf[kk].reshape(ref.shape).cpu()) <= 0.03, kk

@@ -61,6 +61,9 @@ SIGNATURES = {
     "frl_tcn_block_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, F, I, P, S, P]),
     "frl_tcn_block_bwd_data": (c_int, [P, P, P, P, P, L, I, I, I, I, I, I, P, S, P]),
     "frl_tcn_block_bwd_workspace_bytes": (S, [L, I]),
+    "frl_tcn_block_bwd_fused_supported": (c_int, [I, I, I, I, I, I]),
+    "frl_tcn_block_bwd_fused_workspace_bytes": (S, [L]),
+    "frl_tcn_block_bwd_fused": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, F, P, S, P]),
     "frl_tcn_block_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, F, I, P, S, P]),
 }
 
