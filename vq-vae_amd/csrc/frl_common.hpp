@@ -64,6 +64,14 @@ __device__ __forceinline__ float act_fwd(float v, int act) {
   if (act == FRL_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
   return v;
 }
+// fast sigmoid for the bf16 (performance-mode) kernels: v_exp_f32 + v_rcp_f32, ~1e-7 relative error
+__device__ __forceinline__ float sigmoid_fast(float v) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896f * v));
+}
+template <typename T> __device__ __forceinline__ float sigmoid_t(float v) {
+  if constexpr (sizeof(T) == 2) return sigmoid_fast(v); else return 1.f / (1.f + expf(-v));
+}
+
 // derivative expressed through the activation OUTPUT y
 __device__ __forceinline__ float act_bwd_from_y(float y, int act) {
   if (act == FRL_ACT_RELU) return y > 0.f ? 1.f : 0.f;

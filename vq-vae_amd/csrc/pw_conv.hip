@@ -73,6 +73,19 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(
       for (int t = 0; t < NT; ++t) {
         if (rows[t] >= P) continue;
         T* yp = Y + rows[t] * (int64_t)Cout;
+        if (nmb == 4 && (MB & 1) == 0 && (Cout & 15) == 0) {
+          // full chunk: the lane's 16 output channels are contiguous -> 16-byte stores (2 for bf16, 4 for f32)
+          const int cb = qo * kc + 4 * c0;
+          float v[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const float b = bias != nullptr ? bias[cb + j] : 0.f;
+            v[j] = act_fwd(acc[t][j >> 2][j & 3] + b, act);
+          }
+#pragma unroll
+          for (int j = 0; j < 16; j += DT<T>::VEC) Vec<T>::store(yp + cb + j, v + j);
+          continue;
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           if (m >= nmb) continue;

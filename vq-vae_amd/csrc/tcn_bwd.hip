@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void tcn_block_bwd_kernel(const T* __restrict_
 #pragma unroll
       for (int j = 0; j < Q; ++j) {
         const float dy = lq_get<T, NFO>(dyt, j / FE, j % FE) * vf;
-        const float g = 1.f / (1.f + expf(-(gacc[j >> 2][j & 3] + tbg[j])));
+        const float g = sigmoid_t<T>(gacc[j >> 2][j & 3] + tbg[j]);
         const float o = n[j] > 0.f ? n[j] : 0.f;
         dgp[j] = dy * (o - res[j]) * g * (1.f - g);
         res[j] = dy * (1.f - g);                      // reuse as d res

@@ -116,9 +116,29 @@ __device__ __forceinline__ void lq_store(const LQTile<T, NF>& t, T* __restrict__
   }
 }
 
+// static-group-size versions (cg known at compile time: a handful of adds instead of Q*Q predicated ones)
+template <int Q, int CG>
+__device__ __forceinline__ void group_combine_s(float (&out)[Q], const float (&in)[Q]) {
+#pragma unroll
+  for (int g = 0; g < Q / CG; ++g) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CG; ++j) s += in[g * CG + j];
+#pragma unroll
+    for (int j = 0; j < CG; ++j) out[g * CG + j] = s;
+  }
+}
+template <int Q, int CG>
+__device__ __forceinline__ void group_first_s(float (&out)[Q], const float (&in)[Q]) {
+#pragma unroll
+  for (int j = 0; j < Q; ++j) out[j] = in[(j / CG) * CG];
+}
+
 // In-lane group combine: out[j] = sum over j2 in the same group (j2 / cg == j / cg) of in[j2]
 template <int Q>
 __device__ __forceinline__ void group_combine(float (&out)[Q], const float (&in)[Q], int cg) {
+  if constexpr (Q % 8 == 0) { if (cg == 8) { group_combine_s<Q, 8>(out, in); return; } }
+  if constexpr (Q % 4 == 0) { if (cg == 4) { group_combine_s<Q, 4>(out, in); return; } }
 #pragma unroll
   for (int j = 0; j < Q; ++j) {
     float s = 0.f;
@@ -131,6 +151,8 @@ __device__ __forceinline__ void group_combine(float (&out)[Q], const float (&in)
 // out[j] = in[first channel of j's group]
 template <int Q>
 __device__ __forceinline__ void group_first(float (&out)[Q], const float (&in)[Q], int cg) {
+  if constexpr (Q % 8 == 0) { if (cg == 8) { group_first_s<Q, 8>(out, in); return; } }
+  if constexpr (Q % 4 == 0) { if (cg == 4) { group_first_s<Q, 4>(out, in); return; } }
 #pragma unroll
   for (int j = 0; j < Q; ++j) {
     float s = 0.f;

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void tcn_fused_bwd_kernel(const TT* __restrict
 #pragma unroll
       for (int j = 0; j < Q; ++j) {
         const float dy = lq_get<TT, NFO>(dyt, j / FE, j % FE) * vf;
-        const float g = 1.f / (1.f + expf(-(gacc[j >> 2][j & 3] + tbg[j])));
+        const float g = sigmoid_t<TT>(gacc[j >> 2][j & 3] + tbg[j]);
         const float o = n[j] > 0.f ? n[j] : 0.f;
         const float res = lq_get<TT, NFI>(xt, j / FE, j % FE);
         dgp[j] = dy * (o - res) * g * (1.f - g);

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void tcn_block_fwd_kernel(const T* __restrict_
       }
 #pragma unroll
       for (int j = 0; j < Q; ++j) {
-        const float g = 1.f / (1.f + expf(-(gacc[j >> 2][j & 3] + tbg[j])));
+        const float g = sigmoid_t<T>(gacc[j >> 2][j & 3] + tbg[j]);
         const float o = n[j] > 0.f ? n[j] : 0.f;
         y[j] = g * o + (1.f - g) * y[j];
       }
