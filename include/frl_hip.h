@@ -136,6 +136,18 @@ int frl_mse_fwd(const void* pred, const void* target, const uint8_t* mask, int64
 int frl_mse_bwd(const void* pred, const void* target, const uint8_t* mask, const float* gscale, const float* stats,
                 int64_t P, int C, void* dpred, int dtype, frl_stream_t stream);
 
+/* fused decoder + loss (bf16, hidden 128, 64 features, latent <= 64 ch): xhat = W2 relu(W1 z + b1) + b2, L = mean_valid (xhat - x)^2.
+ * Replaces the conv1x1 -> ReLU -> conv1x1 -> reconstruction_loss chain (heads.py:128-198 template, reconstruction.py:95-139) and its
+ * backward with two launches; the hidden tensor and xhat stay on chip (xhat is written only when a buffer is passed). */
+int frl_decoder_mse_fused_supported(int Cz, int hidden, int F, int dtype);
+size_t frl_decoder_mse_workspace_bytes(int64_t P, int Cz);
+int frl_decoder_mse_fwd(const void* z, const float* w1, const float* b1, const float* w2, const float* b2, const void* target,
+                        const uint8_t* mask, void* xhat, float* out, int64_t P, int Cz, void* ws, size_t ws_bytes,
+                        frl_stream_t stream);
+int frl_decoder_mse_bwd(const void* z, const float* w1, const float* b1, const float* w2, const float* b2, const void* target,
+                        const uint8_t* mask, const float* gscale, const float* stats, void* dz, float* dw1, float* db1,
+                        float* dw2, float* db2, int64_t P, int Cz, void* ws, size_t ws_bytes, frl_stream_t stream);
+
 /* ---- vector quantizer ------------------------------------------------------------------------------------------
  * Not in the reference tree; constants frl/config/frl_model_v0.yaml:29-35,
  * scripts/train_vqvae.py:410-436.  idx bit-exact vs float64 argmin (first index on ties). */

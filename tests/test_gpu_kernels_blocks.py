@@ -255,3 +255,35 @@ def test_tcn_block_bwd_fused_matches_oracle_and_unfused(B, T, HW, dil):
         ref = ref_st[p + nm].grad
         assert rel_err(fused[kk].reshape(ref.shape), ref) <= 0.1, kk
         assert rel_err(fused[kk].reshape(ref.shape), unf[kk].reshape(ref.shape).cpu()) <= 0.03, kk
+
+
+@pytest.mark.parametrize("P,cz,use_mask", [(4096, 64, False), (5000, 12, True), (333, 12, False), (1000, 32, True), (130, 64, True)])
+def test_fused_decoder_mse(P, cz, use_mask):
+    """Fused decoder + L2 loss (bf16) vs float64 autograd of the same chain, and vs the modular kernels."""
+    from frl_hip import functional as Fh
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(P + cz)
+    z = q(torch.randn(P, cz, generator=g), dtype).requires_grad_(True)
+    tgt = q(torch.randn(P, 64, generator=g), dtype)
+    w1 = torch.randn(128, cz, generator=g) / cz ** 0.5
+    b1 = torch.randn(128, generator=g) * 0.1
+    w2 = torch.randn(64, 128, generator=g) / 128 ** 0.5
+    b2 = torch.randn(64, generator=g) * 0.1
+    w1q, w2q = q(w1, dtype).requires_grad_(True), q(w2, dtype).requires_grad_(True)
+    b1d, b2d = b1.double().requires_grad_(True), b2.double().requires_grad_(True)
+    mask = (torch.rand(P, generator=g) > 0.25) if use_mask else None
+    hid = torch.relu(z @ w1q.t() + b1d)
+    hid_q = q(hid.detach(), dtype) + (hid - hid.detach())          # the kernel rounds the hidden activations to bf16
+    xh = hid_q @ w2q.t() + b2d
+    loss = O.reconstruction_loss_l2(xh, tgt, mask.unsqueeze(1).expand(P, 64) if use_mask else None)
+    (0.8 * loss).backward()
+    dev = lambda t: t.to(DEV)
+    zd = z.detach().to(dtype).to(DEV).requires_grad_(True)
+    params = [dev(w1).requires_grad_(True), dev(b1).requires_grad_(True), dev(w2).requires_grad_(True), dev(b2).requires_grad_(True)]
+    l, xhat = Fh.decoder_mse(zd, params[0], params[1], params[2], params[3], tgt.to(dtype).to(DEV), mask.to(DEV) if use_mask else None, True)
+    assert abs(l.item() - loss.item()) <= 2e-3 * loss.item()
+    assert rel_err(xhat.float(), xh.detach()) <= 2e-2
+    (0.8 * l).backward()
+    assert rel_err(zd.grad.float(), z.grad) <= 3e-2
+    for got, ref in zip(params, (w1q, b1d, w2q, b2d)):
+        assert rel_err(got.grad, ref.grad) <= 3e-2

@@ -26,13 +26,13 @@ template <typename T> struct C3 {
 // staging helpers
 // ------------------------------------------------------------------------------------------------
 // halo[(hy*18+hx)*pitch + c] = X[b, y0+hy-1, x0+hx-1, ck + c] (* act'(mask)) or 0
-template <typename T>
+template <typename T, int TH = C3_TH, int NTHR = 256>
 __device__ __forceinline__ void stage_halo(T* __restrict__ halo, int pitch, const T* __restrict__ X, const T* __restrict__ M,
                                            int mask_act, int b, int y0, int x0, int H, int W, int C, int ck, int CK, int tid) {
   constexpr int V = DT<T>::VEC;
   const int vpc = CK / V;
   const bool fast = (C % V) == 0;
-  for (int i = tid; i < C3_HP * C3_WP * vpc; i += 256) {
+  for (int i = tid; i < (TH + 2) * C3_WP * vpc; i += NTHR) {
     const int px = i / vpc, c0 = (i % vpc) * V;
     const int hy = px / C3_WP, hx = px % C3_WP;
     const int gy = y0 + hy - 1, gx = x0 + hx - 1;
@@ -99,8 +99,9 @@ __global__ void c3_pack_kernel(typename DT<T>::frag_t* __restrict__ dst, const f
   }
 }
 
+#define C3F_TH 16      // forward / bwd_data tile: 16 x 16 pixels, 8 waves x 2 rows (2 waves per SIMD hide the staging latency)
 template <typename T, int NF>
-__global__ __launch_bounds__(256) void conv3x3_kernel(const T* __restrict__ X, const T* __restrict__ Xmask, int mask_act,
+__global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, const T* __restrict__ Xmask, int mask_act,
                                                       const typename DT<T>::frag_t* __restrict__ Wpk,
                                                       const float* __restrict__ bias, T* __restrict__ Y, int B, int H, int W,
                                                       int Cin, int Cout, int act) {
@@ -110,13 +111,13 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const T* __restrict__ X, c
   constexpr int pitch = CK + C3<T>::PADE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* halo = reinterpret_cast<T*>(smem);
-  frag_t* wl = reinterpret_cast<frag_t*>(smem + (size_t)C3_HP * C3_WP * pitch * sizeof(T));
+  frag_t* wl = reinterpret_cast<frag_t*>(smem + (size_t)(C3F_TH + 2) * C3_WP * pitch * sizeof(T));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, kc = lane >> 4;
-  const int tiles_x = (W + C3_TW - 1) / C3_TW, tiles_y = (H + C3_TH - 1) / C3_TH;
+  const int tiles_x = (W + C3_TW - 1) / C3_TW, tiles_y = (H + C3F_TH - 1) / C3F_TH;
   const int bid = blockIdx.x;
   const int b = bid / (tiles_x * tiles_y), tyx = bid % (tiles_x * tiles_y);
-  const int y0 = (tyx / tiles_x) * C3_TH, x0 = (tyx % tiles_x) * C3_TW;
+  const int y0 = (tyx / tiles_x) * C3F_TH, x0 = (tyx % tiles_x) * C3_TW;
   const int MB = (Cout + 15) >> 4, qo = 4 * MB;
 
   for (int oc0 = 0; oc0 < MB; oc0 += 4) {
@@ -128,9 +129,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const T* __restrict__ X, c
       for (int m = 0; m < 4; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int ck = 0; ck < Cin; ck += CK) {
       __syncthreads();
-      stage_halo<T>(halo, pitch, X, Xmask, mask_act, b, y0, x0, H, W, Cin, ck, CK, tid);
+      stage_halo<T, C3F_TH, 512>(halo, pitch, X, Xmask, mask_act, b, y0, x0, H, W, Cin, ck, CK, tid);
       // weights of this (out-chunk, in-chunk): wl[((tap*4 + m)*NF + s)*64 + lane], copied from the packed image
-      copy_frags_lds<T>(wl, Wpk + (size_t)((oc0 / 4) * ((Cin + CK - 1) / CK) + ck / CK) * (9 * 4 * NF * 64), 9 * 4 * NF * 64, tid, 256);
+      copy_frags_lds<T>(wl, Wpk + (size_t)((oc0 / 4) * ((Cin + CK - 1) / CK) + ck / CK) * (9 * 4 * NF * 64), 9 * 4 * NF * 64, tid, 512);
       __syncthreads();
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
@@ -357,11 +358,11 @@ static int launch_c3(const void* x, const void* xm, int mask_act, const float* w
   const size_t nfrag = (size_t)((MBt + 3) / 4) * ((Cin + CK - 1) / CK) * 9 * 4 * NF * 64;
   if (ws == nullptr || ws_bytes < nfrag * sizeof(frag_t)) return frl_fail(-4, "conv3x3: workspace too small for the packed weights");
   FRL_LAUNCH((c3_pack_kernel<T, NF>), dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, (frag_t*)ws, w, so, si, tap_rev, Cin, Cout);
-  const size_t lds = (size_t)C3_HP * C3_WP * (CK + C3<T>::PADE) * sizeof(T) + (size_t)9 * 4 * NF * 64 * sizeof(frag_t);
+  const size_t lds = (size_t)(C3F_TH + 2) * C3_WP * (CK + C3<T>::PADE) * sizeof(T) + (size_t)9 * 4 * NF * 64 * sizeof(frag_t);
   auto kern = conv3x3_kernel<T, NF>;
   FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int tiles = B * ((H + C3_TH - 1) / C3_TH) * ((W + C3_TW - 1) / C3_TW);
-  FRL_LAUNCH(kern, dim3(tiles), dim3(256), lds, st, (const T*)x, (const T*)xm, mask_act, (const frag_t*)ws, bias, (T*)y, B,
+  const int tiles = B * ((H + C3F_TH - 1) / C3F_TH) * ((W + C3_TW - 1) / C3_TW);
+  FRL_LAUNCH(kern, dim3(tiles), dim3(512), lds, st, (const T*)x, (const T*)xm, mask_act, (const frag_t*)ws, bias, (T*)y, B,
                      H, W, Cin, Cout, act);
   return frl_check_launch("conv3x3");
 }

@@ -221,6 +221,34 @@ class MseFn(Function):
         return ops.mse_bwd(pred, target, mask, g.reshape(1).float().contiguous(), stats), None, None
 
 
+class DecoderMseFn(Function):
+    """Fused conv1x1 -> ReLU -> conv1x1 -> masked L2 loss: (z, W1, b1, W2, b2, target, mask) -> (loss, xhat | None)."""
+
+    @staticmethod
+    def forward(ctx, z, w1, b1, w2, b2, target, mask, want_xhat):
+        stats, xhat = ops.decoder_mse_fwd(z, w1, b1, w2, b2, target, mask, want_xhat)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(z, w1, b1, w2, b2, target, mask, stats)
+        if xhat is not None:
+            ctx.mark_non_differentiable(xhat)
+        return stats[0].clone(), xhat
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, g_xhat):
+        z, w1, b1, w2, b2, target, mask, stats = ctx.saved_tensors
+        if g is None:
+            return (None,) * 8
+        dz, dw1, db1, dw2, db2 = ops.decoder_mse_bwd(z, w1, b1, w2, b2, target, mask, g.reshape(1).float().contiguous(), stats)
+        return dz, dw1.reshape(w1.shape), db1, dw2.reshape(w2.shape), db2, None, None, None
+
+
+def decoder_mse(z, w1, b1, w2, b2, target, mask=None, want_xhat=False):
+    if mask is not None:
+        mask = mask.reshape(-1).to(torch.uint8).contiguous()
+    return DecoderMseFn.apply(z, w1, b1, w2, b2, target, mask, want_xhat)
+
+
 def conv1x1(x, w, bias=None, act=ACT_NONE):
     return Conv1x1Fn.apply(x, w, bias, act)
 

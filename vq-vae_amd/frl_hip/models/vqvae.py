@@ -76,13 +76,28 @@ class VQVAE(RepresentationModel):
             if phase_codebook_size:
                 self.quant_phase = VectorQuantizer(phase_codebook_size, self.z_phase_dim, beta, quantizer, ema_decay, ema_eps)
         self.codebook_manager = None
+        self.fused_decoder = True
 
     def attach_codebook_manager(self, manager) -> None:
         """scripts/train_vqvae.py:197-198: the manager tracks usage / dead codes from `quant.last_counts`."""
         self.codebook_manager = manager
 
-    def forward_tiles(self, tile: torch.Tensor, mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-        """tile [B,T,H,W,F] (any float dtype, GPU) -> dict(loss, l_type, l_phase, vq_loss, perplexity, idx, ...)."""
+    def _decode_loss(self, dec: Conv2DHead, z: torch.Tensor, target: torch.Tensor, mask, want_recon: bool):
+        """Decoder + masked L2.  Hot configuration (bf16, hidden 128, 64 features): one fused kernel per direction, the
+        reconstruction is materialised only on request; otherwise the modular conv1x1 / MSE kernels."""
+        l0, l2 = dec.layers[0], dec.layers[-1]
+        if (len(dec.layers) == 3 and self.fused_decoder
+                and ops.decoder_mse_supported(z.shape[-1], l0.out_channels, l2.out_channels, z)):
+            w1 = l0.weight.reshape(l0.out_channels, l0.in_channels)
+            w2 = l2.weight.reshape(l2.out_channels, l2.in_channels)
+            return Fh.decoder_mse(z, w1, l0.bias, w2, l2.bias, target, mask, want_recon)
+        xhat = dec(z)
+        return Fh.mse_loss(xhat, target, mask), xhat
+
+    def forward_tiles(self, tile: torch.Tensor, mask: Optional[torch.Tensor] = None,
+                      return_recon: bool = False) -> Dict[str, torch.Tensor]:
+        """tile [B,T,H,W,F] (any float dtype, GPU) -> dict(loss, l_type, l_phase, vq_loss, perplexity, idx, ...).
+        `xhat_type` / `xhat_phase` are present when return_recon=True or when the modular decoder path is taken."""
         self._require_gpu(tile)
         tile = self._rows(tile)
         b, t, hh, ww, f = tile.shape
@@ -91,9 +106,10 @@ class VQVAE(RepresentationModel):
         z_type, gate = self.forward_nhwc(x_type, return_gate=True)          # [B,H,W,d]
         d = z_type.shape[-1]
         zq, vq_loss, perp, idx = self.quant(z_type.reshape(-1, d))
-        xhat_type = self.decoder_type(zq.reshape(b, hh, ww, d))
-        l_type = Fh.mse_loss(xhat_type, x_type, mask)
-        out = dict(z_type=z_type, gate=gate, idx=idx, vq_loss=vq_loss, perplexity=perp, xhat_type=xhat_type, l_type=l_type)
+        l_type, xhat_type = self._decode_loss(self.decoder_type, zq.reshape(b, hh, ww, d), x_type, mask, return_recon)
+        out = dict(z_type=z_type, gate=gate, idx=idx, vq_loss=vq_loss, perplexity=perp, l_type=l_type)
+        if xhat_type is not None:
+            out["xhat_type"] = xhat_type
         loss = self.lambda_recon * l_type + self.lambda_vq * vq_loss
         if self.phase:
             z_phase = self.forward_phase_nhwc(tile, z_type.detach())       # [B,T,H,W,zp]
@@ -103,11 +119,12 @@ class VQVAE(RepresentationModel):
                 zp_in = zpq.reshape(z_phase.shape)
                 loss = loss + self.lambda_vq * pvq
                 out.update(idx_phase=pidx, vq_loss_phase=pvq, perplexity_phase=pperp)
-            xhat_phase = self.decoder_phase(zp_in)
             pmask = None if mask is None else mask.unsqueeze(1).expand(b, t, hh, ww).contiguous()
-            l_phase = Fh.mse_loss(xhat_phase, tile, pmask)
+            l_phase, xhat_phase = self._decode_loss(self.decoder_phase, zp_in, tile, pmask, return_recon)
             loss = loss + self.lambda_recon * l_phase
-            out.update(z_phase=z_phase, xhat_phase=xhat_phase, l_phase=l_phase)
+            out.update(z_phase=z_phase, l_phase=l_phase)
+            if xhat_phase is not None:
+                out["xhat_phase"] = xhat_phase
         out["loss"] = loss
         if self.codebook_manager is not None and hasattr(self.codebook_manager, "update"):
             self.codebook_manager.update(self.quant.last_counts)
@@ -118,6 +135,6 @@ class VQVAE(RepresentationModel):
 
         A tensor argument keeps the RepresentationModel.forward semantics ([B,C,H,W] -> z_type)."""
         if isinstance(batch, dict):
-            out = self.forward_tiles(batch["tile"], batch.get("mask"))
+            out = self.forward_tiles(batch["tile"], batch.get("mask"), return_recon=True)
             return out["xhat_type"], {}, out.get("xhat_phase"), out["vq_loss"], out["perplexity"]
         return super().forward(batch, return_gate)

@@ -470,3 +470,38 @@ def tcn_block_bwd(x, dy, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, pro
         dpw, dpb = _conv1x1_bwd_weight_impl(dres, x)
         out.update(proj_w=dpw.reshape(proj_w.shape), proj_b=dpb)
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# fused decoder + reconstruction loss (csrc/dec_fused.hip)
+# ----------------------------------------------------------------------------------------------
+def decoder_mse_supported(cz: int, hidden: int, features: int, t: torch.Tensor) -> bool:
+    return bool(_lib.load().frl_decoder_mse_fused_supported(cz, hidden, features, _dt(t)))
+
+
+@_timed("decoder_mse_fwd")
+def decoder_mse_fwd(z, w1, b1, w2, b2, target, mask=None, want_xhat: bool = False):
+    """z [..., Cz], target [..., 64] -> (stats f32 [2] = {mse, n_valid}, xhat or None)."""
+    cz = z.shape[-1]
+    p = z.numel() // cz
+    lib = _lib.load()
+    ws = workspace(lib.frl_decoder_mse_workspace_bytes(p, cz), z.device)
+    out = torch.empty(2, dtype=torch.float32, device=z.device)
+    xhat = torch.empty_like(target) if want_xhat else None
+    check(lib.frl_decoder_mse_fwd(_p(z), _p(w1), _p(b1), _p(w2), _p(b2), _p(target), _p(mask), _p(xhat), _p(out), p, cz, _p(ws),
+                                  ws.numel(), _stream()), "frl_decoder_mse_fwd")
+    return out, xhat
+
+
+@_timed("decoder_mse_bwd")
+def decoder_mse_bwd(z, w1, b1, w2, b2, target, mask, gscale, stats):
+    cz = z.shape[-1]
+    p = z.numel() // cz
+    lib = _lib.load()
+    ws = workspace(lib.frl_decoder_mse_workspace_bytes(p, cz), z.device)
+    dz = torch.empty_like(z)
+    dw1, db1 = torch.empty_like(w1, dtype=torch.float32), torch.empty_like(b1, dtype=torch.float32)
+    dw2, db2 = torch.empty_like(w2, dtype=torch.float32), torch.empty_like(b2, dtype=torch.float32)
+    check(lib.frl_decoder_mse_bwd(_p(z), _p(w1), _p(b1), _p(w2), _p(b2), _p(target), _p(mask), _p(gscale), _p(stats), _p(dz), _p(dw1),
+                                  _p(db1), _p(dw2), _p(db2), p, cz, _p(ws), ws.numel(), _stream()), "frl_decoder_mse_bwd")
+    return dz, dw1, db1, dw2, db2
