@@ -192,23 +192,25 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
 // ------------------------------------------------------------------------------------------------
 // bwd_weight
 // ------------------------------------------------------------------------------------------------
-template <typename T, int IBC, int OBW>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict__ dY, const T* __restrict__ Ymask, int mask_act,
+// NWV waves per workgroup, spatial tile WTH x 16 pixels (WTH = 2 * NWV): 8 waves = 2 per SIMD hide the staging latency
+template <typename T, int IBC, int OBW, int NWV>
+__global__ __launch_bounds__(64 * NWV) void conv3x3_wgrad_kernel(const T* __restrict__ dY, const T* __restrict__ Ymask, int mask_act,
                                                             const T* __restrict__ X, float* __restrict__ slab, int B, int H, int W,
                                                             int Cin, int Cout, int oc_base, int tiles_per_wg, int use_tr) {
   constexpr int FE = DT<T>::FE;
   constexpr int V = DT<T>::VEC;
   constexpr int CK = IBC * 16;
-  constexpr int NOG = 4 / IBC;                 // wave groups along output channels
+  constexpr int NOG = NWV / IBC;               // wave groups along output channels
+  constexpr int WTH = 2 * NWV, NTHR = 64 * NWV;
   constexpr int OCT = NOG * OBW * 16;          // output channels per pass (64)
   constexpr int pitchA = OCT + C3<T>::PADE, pitchB = CK + C3<T>::PADE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* ldsA = reinterpret_cast<T*>(smem);                                   // [128][pitchA]
-  T* halo = ldsA + C3_TH * C3_TW * pitchA;                                // [180][pitchB]
+  T* halo = ldsA + WTH * C3_TW * pitchA;                                // [180][pitchB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, kc = lane >> 4;
   const int ib = wave % IBC, og = wave / IBC;
-  const int tiles_x = (W + C3_TW - 1) / C3_TW, tiles_y = (H + C3_TH - 1) / C3_TH;
+  const int tiles_x = (W + C3_TW - 1) / C3_TW, tiles_y = (H + WTH - 1) / WTH;
   const int ntiles = B * tiles_x * tiles_y;
   const int t_begin = blockIdx.x * tiles_per_wg;
   const int t_end = (t_begin + tiles_per_wg) < ntiles ? (t_begin + tiles_per_wg) : ntiles;
@@ -225,10 +227,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict_
       for (int o = 0; o < OBW; ++o) acc[tap][o] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int tile = t_begin; tile < t_end; ++tile) {
       const int b = tile / (tiles_x * tiles_y), tyx = tile % (tiles_x * tiles_y);
-      const int y0 = (tyx / tiles_x) * C3_TH, x0 = (tyx % tiles_x) * C3_TW;
+      const int y0 = (tyx / tiles_x) * WTH, x0 = (tyx % tiles_x) * C3_TW;
       __syncthreads();
       // dY tile (masked by act'(y)), channels [oc_base, oc_base + OCT)
-      for (int i = tid; i < C3_TH * C3_TW * (OCT / V); i += 256) {
+      for (int i = tid; i < WTH * C3_TW * (OCT / V); i += NTHR) {
         const int px = i / (OCT / V), c0 = (i % (OCT / V)) * V;
         const int gy = y0 + px / C3_TW, gx = x0 + px % C3_TW;
         float v[V];
@@ -255,16 +257,16 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict_
         }
         Vec<T>::store(ldsA + px * pitchA + c0, v);
       }
-      stage_halo<T>(halo, pitchB, X, (const T*)nullptr, 0, b, y0, x0, H, W, Cin, ck, CK, tid);
+      stage_halo<T, WTH, NTHR>(halo, pitchB, X, (const T*)nullptr, 0, b, y0, x0, H, W, Cin, ck, CK, tid);
       __syncthreads();
       if (ck == 0 && tid < OCT) {
         float s = 0.f;
-        for (int p = 0; p < C3_TH * C3_TW; ++p) s += to_f32(ldsA[p * pitchA + tid]);
+        for (int p = 0; p < WTH * C3_TW; ++p) s += to_f32(ldsA[p * pitchA + tid]);
         bsum += s;
       }
       if constexpr (FE == 8) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll 1
+        for (int ks = 0; ks < WTH / 2; ++ks) {
           const int row = 2 * ks + (kc >> 1), col = 8 * (kc & 1);
           bf16x8 af[OBW];
 #pragma unroll
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict_
         }
       } else {
 #pragma unroll 2
-        for (int ks = 0; ks < C3_TH * C3_TW / 4; ++ks) {
+        for (int ks = 0; ks < WTH * C3_TW / 4; ++ks) {
           const int pix = 4 * ks + kc;
           const int row = pix / C3_TW, col = pix % C3_TW;
           float af[OBW];
@@ -381,8 +383,9 @@ static int c3_dispatch(const void* x, const void* xm, int mask_act, const float*
   return frl_fail(-2, "conv3x3: bad dtype");
 }
 
+#define C3W_TH 16     // wgrad spatial tile height (8 waves x 2 rows)
 static int c3_wgrad_nwg(int B, int H, int W) {
-  const int tiles = B * ((H + C3_TH - 1) / C3_TH) * ((W + C3_TW - 1) / C3_TW);
+  const int tiles = B * ((H + C3W_TH - 1) / C3W_TH) * ((W + C3_TW - 1) / C3_TW);
   return tiles < 256 ? tiles : 256;
 }
 
@@ -411,21 +414,22 @@ int frl_conv3x3_bwd_weight(const void* dy, const void* y, int act, const void* x
                            int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, int flags, hipStream_t stream) {
   if (ws_bytes < frl_conv3x3_bwd_weight_workspace_bytes(B, H, W, Cin, Cout)) return frl_fail(-4, "conv3x3_bwd_weight: workspace too small");
   const int nwg = c3_wgrad_nwg(B, H, W);
-  const int tiles = B * ((H + C3_TH - 1) / C3_TH) * ((W + C3_TW - 1) / C3_TW);
+  const int tiles = B * ((H + C3W_TH - 1) / C3W_TH) * ((W + C3_TW - 1) / C3_TW);
   const int tpw = (tiles + nwg - 1) / nwg;
   const void* ym = act != FRL_ACT_NONE ? y : nullptr;
   const int64_t slab_n = (int64_t)64 * Cin * 9 + 64;
   for (int oc_base = 0; oc_base < Cout; oc_base += 64) {
     if (dtype == FRL_F32) {
-      const size_t lds = ((size_t)128 * (64 + 4) + (size_t)180 * (32 + 4)) * 4;
-      auto kern = conv3x3_wgrad_kernel<float, 2, 2>;
+      const size_t lds = ((size_t)256 * (64 + 4) + (size_t)18 * 18 * (32 + 4)) * 4;
+      auto kern = conv3x3_wgrad_kernel<float, 2, 1, 8>;
       FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      FRL_LAUNCH(kern, dim3(nwg), dim3(256), lds, stream, (const float*)dy, (const float*)ym, act, (const float*)x, (float*)ws,
+      FRL_LAUNCH(kern, dim3(nwg), dim3(512), lds, stream, (const float*)dy, (const float*)ym, act, (const float*)x, (float*)ws,
                          B, H, W, Cin, Cout, oc_base, tpw, 0);
     } else if (dtype == FRL_BF16) {
-      const size_t lds = ((size_t)128 * (64 + 8) + (size_t)180 * (64 + 8)) * 2;
-      auto kern = conv3x3_wgrad_kernel<bf16, 4, 4>;
-      FRL_LAUNCH(kern, dim3(nwg), dim3(256), lds, stream, (const bf16*)dy, (const bf16*)ym, act, (const bf16*)x, (float*)ws, B,
+      const size_t lds = ((size_t)256 * (64 + 8) + (size_t)18 * 18 * (64 + 8)) * 2;
+      auto kern = conv3x3_wgrad_kernel<bf16, 4, 2, 8>;
+      FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      FRL_LAUNCH(kern, dim3(nwg), dim3(512), lds, stream, (const bf16*)dy, (const bf16*)ym, act, (const bf16*)x, (float*)ws, B,
                          H, W, Cin, Cout, oc_base, tpw, (flags & 1) ? 0 : 1);
     } else return frl_fail(-2, "conv3x3_bwd_weight: bad dtype");
     launch_slab_reduce<float, C3Epi>((const float*)ws, nwg, slab_n, C3Epi{64, Cin * 9, oc_base, Cout, dw, dbias}, stream);

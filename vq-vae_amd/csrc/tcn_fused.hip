@@ -109,8 +109,9 @@ __global__ __launch_bounds__(256) void tcn_fused_bwd_kernel(const TT* __restrict
     if (!valid) pidx = a.npix - 1;
     const int64_t b = pidx / a.HW, hw = pidx % a.HW;
     const int64_t row0 = b * a.Tn * a.HW + hw;
-    XCache<TT, NFI, TP> xc;
+    XCache<TT, NFI, TP> xc, dyc, drc;                       // x, dy (prefetched in one batch) and dres (kept for pass 4) time series
     xcache_load<TT, NFI, TP>(xc, X, row0, a, TF_C, kc, true);
+    xcache_load<TT, NFI, TP>(dyc, DY, row0, a, TF_C, kc, true);
     float rs[Q], sh[Q];
     tcn_stats<TT, NFI, MBO, TP>(rs, sh, xc, X, row0, a, kc, true, wl_conv, bc, lane);
     float S1[Q], S2[Q];
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void tcn_fused_bwd_kernel(const TT* __restrict
       LQTile<TT, NFI> xt;
       xcache_get<TT, NFI, TP>(xt, xc, X, row0, a, t, TF_C, kc, true);
       LQTile<TT, NFO> dyt;
-      lq_load<TT, NFO>(dyt, DY, row, TF_C, kc, true);
+      xcache_get<TT, NFO, TP>(dyt, dyc, DY, row0, a, t, TF_C, kc, true);
       float dgp[Q], dn[Q], dr[Q];
 #pragma unroll
       for (int j = 0; j < Q; ++j) {
@@ -167,10 +168,10 @@ __global__ __launch_bounds__(256) void tcn_fused_bwd_kernel(const TT* __restrict
       LQTile<TT, NFO> tt;
       acc_to_tile<TT, MBO>(tt, dn);
       lds_put(dc_res + t * 64 * TF_PITCH, prow, kc, tt);
-      if (valid) {
-        acc_to_tile<TT, MBO>(tt, dr);
-        lq_store<TT, NFO>(tt, DX, row, TF_C, kc, true);
-      }
+      acc_to_tile<TT, MBO>(tt, dr);
+#pragma unroll
+      for (int u = 0; u < TP; ++u)
+        if (u == t) drc.xs[u] = tt;
       __syncthreads();
       wgrad_tile(accG, accGb, true, exA + buf * 64 * TF_PITCH, exB + buf * 64 * TF_PITCH, wave, r16, kc);
     }
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) void tcn_fused_bwd_kernel(const TT* __restrict
       }
       if (valid) {
         LQTile<TT, NFO> rt;
-        lq_load<TT, NFO>(rt, DX, row, TF_C, kc, true);        // dres written by this lane in pass 2
+        xcache_get<TT, NFO, TP>(rt, drc, DX, row0, a, tp, TF_C, kc, true);   // dres kept in registers since pass 2
         float y[Q];
 #pragma unroll
         for (int j = 0; j < Q; ++j) y[j] = acc[j >> 2][j & 3] + lq_get<TT, NFO>(rt, j / FE, j % FE);

@@ -46,6 +46,31 @@ __global__ void vq_prep_kernel(const float* __restrict__ E, int K, int d, float*
   atomicMax(&hdr->enmax_bits, __float_as_uint(s));
 }
 
+// packed MFMA A-fragment image of -2 * round_T(E): frag index (mb * NF + s) * 64 + lane, code = 16*mb + (lane & 15),
+// channel = q*(lane >> 4) + s*FE + e.  Written once per call; workgroups copy their chunk with 16-byte loads.
+template <typename T, int NF>
+__global__ void vq_pack_kernel(const float* __restrict__ E, int K, int d, typename DT<T>::frag_t* __restrict__ pk, int total) {
+  constexpr int FE = DT<T>::FE;
+  constexpr int q = NF * FE;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ln = i & 63, fs = i >> 6;
+  const int s = fs % NF, mb = fs / NF;
+  const int code = mb * 16 + (ln & 15), kq = ln >> 4;
+  if constexpr (FE == 8) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = q * kq + 8 * s + e;
+      v[e] = (code < K && ch < d) ? (bf16)(-2.f * (float)(bf16)E[(int64_t)code * d + ch]) : (bf16)0.f;
+    }
+    pk[i] = v;
+  } else {
+    const int ch = q * kq + s;
+    pk[i] = (code < K && ch < d) ? -2.f * E[(int64_t)code * d + ch] : 0.f;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // main assignment kernel
 // ---------------------------------------------------------------------------------------------
@@ -54,7 +79,7 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(
     const T* __restrict__ Z, const float* __restrict__ E, const float* __restrict__ en_g, const VqHeader* __restrict__ hdr,
     int64_t N, int K, int d, int Kc, int32_t* __restrict__ idx_out, T* __restrict__ zq_out,
     float* __restrict__ partial /*[grid*4]*/, int32_t* __restrict__ hist_slab /*[grid][K]*/, VqHeader* __restrict__ hdr_w,
-    int32_t* __restrict__ amb_list) {
+    int32_t* __restrict__ amb_list, const typename DT<T>::frag_t* __restrict__ pk) {
   typedef typename DT<T>::frag_t frag_t;
   constexpr int FE = DT<T>::FE;
   constexpr int q = NF * FE;                 // channels per lane quarter
@@ -104,24 +129,7 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(
       if (filled_chunk != c) {
         __syncthreads();
         const int kbase = c * Kc;
-        const int total = (Kc / 16) * NF * 64;
-        for (int i = tid; i < total; i += 256) {
-          const int ln = i & 63, fs = i >> 6;
-          const int s = fs % NF, mb = fs / NF;
-          const int code = kbase + mb * 16 + (ln & 15), kq = ln >> 4;
-          if constexpr (FE == 8) {
-            bf16x8 v;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const int ch = q * kq + 8 * s + e;
-              v[e] = (code < K && ch < d) ? (bf16)(-2.f * (float)(bf16)E[(int64_t)code * d + ch]) : (bf16)0.f;
-            }
-            wl[i] = v;
-          } else {
-            const int ch = q * kq + s;
-            wl[i] = (code < K && ch < d) ? -2.f * E[(int64_t)code * d + ch] : 0.f;
-          }
-        }
+        copy_frags_lds<T>(wl, pk + (size_t)(kbase / 16) * NF * 64, (Kc / 16) * NF * 64, tid, 256);
         for (int i = tid; i < Kc; i += 256) enl[i] = (kbase + i < K) ? en_g[kbase + i] : 3.0e38f;
         __syncthreads();
         filled_chunk = c;
@@ -308,9 +316,21 @@ __global__ __launch_bounds__(256) void vq_fixup_lds_kernel(const T* __restrict__
   float* zrow = et + (size_t)K * pitch + (size_t)wave * d;  // [4][d]
   const int namb = hdr->namb;
   if ((int)blockIdx.x * 4 >= namb) return;                  // whole workgroup has no rows: skip the fill
-  for (int i = tid; i < K * d; i += 256) {
-    const int kk = i / d, j = i - kk * d;
-    et[kk * pitch + j] = to_f32(from_f32<T>(E[i]));
+  if ((d & 3) == 0) {
+    const f32x4* E4 = reinterpret_cast<const f32x4*>(E);
+    const int d4 = d >> 2;
+    for (int i = tid; i < K * d4; i += 256) {
+      const int kk = i / d4, j = (i - kk * d4) * 4;
+      const f32x4 v = E4[i];
+      float* dst = et + kk * pitch + j;
+      dst[0] = to_f32(from_f32<T>(v[0])); dst[1] = to_f32(from_f32<T>(v[1]));
+      dst[2] = to_f32(from_f32<T>(v[2])); dst[3] = to_f32(from_f32<T>(v[3]));
+    }
+  } else {
+    for (int i = tid; i < K * d; i += 256) {
+      const int kk = i / d, j = i - kk * d;
+      et[kk * pitch + j] = to_f32(from_f32<T>(E[i]));
+    }
   }
   __syncthreads();
   const int nwaves = gridDim.x * 4;
@@ -472,6 +492,120 @@ __global__ __launch_bounds__(256) void vq_bwd_kernel(const T* __restrict__ gout,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 backward on the matrix cores: code sums S[k][:] = sum_{n: idx_n = k} z_n as the GEMM  onehot(idx)^T * Z  with K = rows.
+// The one-hot A fragments are generated in registers from the staged indices (exact 0/1 in bf16), the z tile is fetched
+// k-strided with ds_read_b64_tr_b16, products are exact and accumulated in f32 in a fixed order -> bit-reproducible,
+// no LDS float atomics.  g_z = g_out + cz (z - e_idx) is fused on the staged tile.
+// Each wave owns RB row blocks (16 codes each) x CB column blocks (16 channels) of the [Kc x d] chunk; chunks of the
+// codebook are an outer loop (z is re-read once per chunk; one chunk covers K <= 512 at d <= 64).
+// ---------------------------------------------------------------------------------------------
+template <int RB, int CB>
+__global__ __launch_bounds__(256) void vq_bwd_mfma_kernel(const bf16* __restrict__ gout, const bf16* __restrict__ Z, const float* __restrict__ E,
+                                                          const int32_t* __restrict__ idx, const float* __restrict__ gscale, float cz_base,
+                                                          int64_t N, int K, int d, int64_t rows_per_wg, bf16* __restrict__ gz,
+                                                          float* __restrict__ slab /*[grid][K][d]*/) {
+  constexpr int DP = CB * 16, PITCH = DP + 8, KC = RB * 4 * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* zt = reinterpret_cast<bf16*>(smem);                      // [64][PITCH]
+  int* it = reinterpret_cast<int*>(zt + 64 * PITCH);             // [64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kc = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  int64_t r1 = r0 + rows_per_wg;
+  if (r1 > N) r1 = N;
+  const float cz = cz_base * (gscale ? gscale[0] : 1.f);
+  const bool fast = (d % 8) == 0;
+  const int vpr = DP / 8;
+  const bf16 one = (bf16)1.f, zero = (bf16)0.f;
+  for (int kbase = 0; kbase < K; kbase += KC) {
+    f32x4 acc[RB][CB];
+#pragma unroll
+    for (int a = 0; a < RB; ++a)
+#pragma unroll
+      for (int b = 0; b < CB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t p0 = r0; p0 < r1; p0 += 64) {
+      __syncthreads();
+      // stage 64 rows of z (zero padded) and their indices; first chunk also writes g_z
+      for (int i = tid; i < 64 * vpr; i += 256) {
+        const int row = i / vpr, c0 = (i % vpr) * 8;
+        const int64_t n = p0 + row;
+        float zv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) zv[e] = 0.f;
+        if (n < r1 && c0 < d) {
+          if (fast) Vec<bf16>::load(Z + n * (int64_t)d + c0, zv);
+          else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (c0 + e < d) zv[e] = (float)Z[n * (int64_t)d + c0 + e];
+          }
+          if (kbase == 0 && gz != nullptr) {
+            const int k = idx[n];
+            float gv[8], ov[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gv[e] = 0.f;
+            if (gout != nullptr) {
+              if (fast) Vec<bf16>::load(gout + n * (int64_t)d + c0, gv);
+              else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (c0 + e < d) gv[e] = (float)gout[n * (int64_t)d + c0 + e];
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float ev = (c0 + e < d) ? (float)(bf16)E[(int64_t)k * d + c0 + e] : 0.f;
+              ov[e] = gv[e] + cz * (zv[e] - ev);
+            }
+            if (fast) Vec<bf16>::store(gz + n * (int64_t)d + c0, ov);
+            else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) if (c0 + e < d) gz[n * (int64_t)d + c0 + e] = (bf16)ov[e];
+            }
+          }
+        }
+        Vec<bf16>::store(zt + row * PITCH + c0, zv);
+      }
+      if (tid < 64) it[tid] = (p0 + tid < r1) ? idx[p0 + tid] - kbase : -1;
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int pix0 = ks * 32 + 8 * kc;
+        int id8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) id8[j] = it[pix0 + j];
+        bf16x8 bfr[CB];
+#pragma unroll
+        for (int b = 0; b < CB; ++b) {
+          const bf16* a0 = zt + (pix0 + (r16 >> 2)) * PITCH + b * 16 + 4 * (r16 & 3);
+          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0));
+          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0 + 4 * PITCH));
+          bfr[b] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int a = 0; a < RB; ++a) {
+          const int code = (wave * RB + a) * 16 + r16;            // chunk-local code of this lane's A row
+          bf16x8 af;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) af[j] = (id8[j] == code) ? one : zero;
+#pragma unroll
+          for (int b = 0; b < CB; ++b) acc[a][b] = mfma16(af, bfr[b], acc[a][b]);
+        }
+      }
+    }
+    float* dst = slab + (int64_t)blockIdx.x * K * d;
+#pragma unroll
+    for (int a = 0; a < RB; ++a)
+#pragma unroll
+      for (int b = 0; b < CB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = kbase + (wave * RB + a) * 16 + kc * 4 + r, c = b * 16 + r16;
+          if (k < K && c < d) dst[(int64_t)k * d + c] = acc[a][b][r];
+        }
+  }
+}
+
+
 // g_E[k][j] = ce * gscale * (n_k * e_k[j] - sum_wg slab[wg][k][j]);  also exports code sums when asked
 template <typename T>
 __global__ void vq_code_reduce_kernel(const float* __restrict__ slab, int nslab, const float* __restrict__ E,
@@ -529,9 +663,9 @@ static int vq_grid(int64_t N, int NT) {
 }
 #define VQ_NT 4
 #define VQ_FIX_WAVES 1024
-#define VQ_BWD_WGS 128
+#define VQ_BWD_WGS 256
 
-struct VqLayout { size_t hdr, en, counts_fix, partial, amb, hist, total; int grid; };
+struct VqLayout { size_t hdr, en, counts_fix, partial, amb, hist, pack, total; int grid; };
 static VqLayout vq_layout(int64_t N, int K) {
   VqLayout L;
   L.grid = vq_grid(N, VQ_NT);
@@ -541,7 +675,8 @@ static VqLayout vq_layout(int64_t N, int K) {
   L.en = o; o += ((size_t)K * 4 + 255) / 256 * 256;
   L.partial = o; o += ((size_t)L.grid * 4 * 4 + 255) / 256 * 256;
   L.amb = o; o += ((size_t)N * 4 + 255) / 256 * 256;
-  L.hist = o; o += (size_t)L.grid * K * 4;
+  L.hist = o; o += ((size_t)L.grid * K * 4 + 255) / 256 * 256;
+  L.pack = o; o += (size_t)((K + 15) / 16 + 32) * 16 * 128 * 4;      // packed codebook, padded to a whole chunk, d_pad <= 128
   L.total = o;
   return L;
 }
@@ -557,12 +692,16 @@ static int launch_vq(const void* z, const float* E, int64_t N, int K, int d, int
   float* en = (float*)(ws + L.en);
   FRL_HIP(hipMemsetAsync(ws, 0, L.en, st));                          // header + counts_fix
   FRL_LAUNCH((vq_prep_kernel<T>), dim3((K + 255) / 256), dim3(256), 0, st, E, K, d, en, hdr);
+  const int kpadc = (K + Kc - 1) / Kc * Kc;                              // whole chunks (codes beyond K pack as zeros, masked by enl)
+  const int npk = (kpadc / 16) * NF * 64;
+  frag_t* pk = (frag_t*)(ws + L.pack);
+  FRL_LAUNCH((vq_pack_kernel<T, NF>), dim3((npk + 255) / 256), dim3(256), 0, st, E, K, d, pk, npk);
   const size_t lds = (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc * 4 + (size_t)K * 4;
   if (lds > 160 * 1024) return frl_fail(-3, "vq_assign: LDS budget exceeded (K too large for histogram)");
   auto kern = vq_assign_kernel<T, NF, VQ_NT>;
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   FRL_LAUNCH(kern, dim3(L.grid), dim3(256), lds, st, (const T*)z, E, en, hdr, N, K, d, Kc, idx, (T*)zq,
-             (float*)(ws + L.partial), (int32_t*)(ws + L.hist), hdr, (int32_t*)(ws + L.amb));
+             (float*)(ws + L.partial), (int32_t*)(ws + L.hist), hdr, (int32_t*)(ws + L.amb), (const frag_t*)pk);
   const size_t fix_lds = (size_t)4 * (d + 64 * (d + 1)) * sizeof(float);
   {
     auto fk = vq_fixup_kernel<T>;
@@ -644,10 +783,17 @@ int frl_vq_bwd(const void* g_out, const void* z, const float* E, const int32_t* 
     FRL_LAUNCH((vq_code_reduce_kernel<float>), dim3((unsigned)(((int64_t)K * d + 255) / 256)), dim3(256), 0, stream,
                        (const float*)slab, VQ_BWD_WGS, E, counts, gscale, ce, K, d, g_E_out, sums_out);
   } else if (dtype == FRL_BF16) {
-    auto kern = vq_bwd_kernel<bf16>;
-    if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    FRL_LAUNCH(kern, dim3(VQ_BWD_WGS), dim3(256), lds, stream, (const bf16*)g_out, (const bf16*)z, E, idx, gscale,
-                       cz, N, K, d, Kc, rows, (bf16*)g_z_out, slab);
+    const int64_t rows64 = (rows + 63) / 64 * 64;
+    if (d <= 32) {
+      FRL_LAUNCH((vq_bwd_mfma_kernel<8, 2>), dim3(VQ_BWD_WGS), dim3(256), (size_t)64 * 40 * 2 + 256, stream, (const bf16*)g_out, (const bf16*)z, E, idx,
+                 gscale, cz, N, K, d, rows64, (bf16*)g_z_out, slab);
+    } else if (d <= 64) {
+      FRL_LAUNCH((vq_bwd_mfma_kernel<8, 4>), dim3(VQ_BWD_WGS), dim3(256), (size_t)64 * 72 * 2 + 256, stream, (const bf16*)g_out, (const bf16*)z, E, idx,
+                 gscale, cz, N, K, d, rows64, (bf16*)g_z_out, slab);
+    } else {
+      FRL_LAUNCH((vq_bwd_mfma_kernel<4, 8>), dim3(VQ_BWD_WGS), dim3(256), (size_t)64 * 136 * 2 + 256, stream, (const bf16*)g_out, (const bf16*)z, E, idx,
+                 gscale, cz, N, K, d, rows64, (bf16*)g_z_out, slab);
+    }
     FRL_LAUNCH((vq_code_reduce_kernel<bf16>), dim3((unsigned)(((int64_t)K * d + 255) / 256)), dim3(256), 0, stream,
                        (const float*)slab, VQ_BWD_WGS, E, counts, gscale, ce, K, d, g_E_out, sums_out);
   } else return frl_fail(-2, "vq_bwd: bad dtype");
