@@ -154,7 +154,7 @@ int frl_decoder_mse_bwd(const void* z, const float* w1, const float* b1, const f
 size_t frl_vq_workspace_bytes(int64_t N, int K, int d);
 int frl_vq_assign_fwd(const void* z, const float* E, int64_t N, int K, int d, int32_t* idx_out, void* zq_out,
                       float* stats_out, int32_t* counts_out, int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
-int frl_vq_bwd(const void* g_out, const void* z, const float* E, const int32_t* idx, const int32_t* counts,
+int frl_vq_bwd(const void* g_out, const void* z, const void* zq /* optional */, const float* E, const int32_t* idx, const int32_t* counts,
                const float* gscale, float beta, int64_t N, int K, int d, void* g_z_out, float* g_E_out, float* sums_out,
                int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
 int frl_vq_ema_update(const float* sums, const int32_t* counts, int K, int d, float decay, float eps, float* ema_count,

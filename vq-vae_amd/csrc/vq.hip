@@ -20,8 +20,8 @@
 #include "frl_reduce.hpp"
 #include <math.h>
 
-#define VQ_IDX_BITS 9
-#define VQ_IDX_MASK 511u
+#define VQ_IDX_BITS 7
+#define VQ_IDX_MASK 127u        // keys carry a 7-bit index inside groups of 128 codes (8 MFMA row blocks)
 #define VQ_MAX_CHUNK 512
 
 struct VqHeader {           // lives at the start of the workspace (zeroed by hipMemsetAsync every call)
@@ -87,13 +87,14 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(
   frag_t* wl = reinterpret_cast<frag_t*>(smem);                       // [Kc/16][NF][64]
   float* enl = reinterpret_cast<float*>(smem + (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t));  // [Kc]
   int* hist = reinterpret_cast<int*>(enl + Kc);                        // [K]
+  unsigned* cbw = reinterpret_cast<unsigned*>(hist + K);               // batch maximum of ||z||^2 (f32 bits)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vx = lane & 15, kc = lane >> 4;
   const int nchunks = (K + Kc - 1) / Kc;
   const bool fast = (d == 4 * q);
   const float enmax = __uint_as_float(hdr->enmax_bits);
-  const float err_rel = (float)(4 * q + 16) * 1.1920929e-7f;           // (d_pad+16) * 2^-23
-  const float thr_rel = 1.220703125e-4f + 2.f * err_rel;               // 2^-13 + 2*err
+  const float err_rel = (float)(4 * q + 8) * 1.1920929e-7f;            // (d_pad+8) * 2^-23: f32 accumulation of exact products
+  const float thr_rel = 3.0517578125e-5f + 2.f * err_rel;              // 2^-(22-7) key truncation of both scores + 2*err
 
   for (int k = tid; k < K; k += 256) hist[k] = 0;
   float sq_acc = 0.f;
@@ -104,9 +105,10 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(
   for (int64_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
     const int64_t v0 = (batch * 4 + wave) * (NT * 16);
     LQTile<T, NF> zt[NT];
-    float biasv[NT], thr[NT];
+    float thr[NT];
     unsigned g1[NT], g2[NT];
     int gc[NT];
+    float zmax = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       int64_t row = v0 + t * 16 + vx;
@@ -119,50 +121,68 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(
         for (int e = 0; e < FE; ++e) { const float v = lq_get<T, NF>(zt[t], s, e); zn = fmaf(v, v, zn); }
       zn += __shfl_xor(zn, 16, 64);
       zn += __shfl_xor(zn, 32, 64);
-      const float extra = 9.765625e-4f * (zn + enmax) + 1e-30f;      // 2^-10 (zn + enmax): keeps scores > 0
-      biasv[t] = zn + extra;
-      const float sroot = sqrtf(zn) + sqrtf(enmax);
-      thr[t] = (sroot * sroot + extra) * thr_rel;
+      zmax = fmaxf(zmax, zn);
       g1[t] = 0xFFFFFFFFu; g2[t] = 0xFFFFFFFFu; gc[t] = 0;
     }
+    // One positive bias per workgroup batch (max ||z||^2 of its 256 vectors, + margin) is folded into the LDS copy of
+    // ||e||^2, so the MFMA accumulator is initialised straight from LDS and every score en + Cb - 2 z.e stays > 0.
+    __syncthreads();
+    if (tid == 0) *cbw = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, off, 64));
+    if (lane == 0) atomicMax(cbw, __float_as_uint(zmax));
+    __syncthreads();
+    const float zbm = __uint_as_float(*cbw);
+    const float Cb = zbm + 9.765625e-4f * (zbm + enmax) + 1e-30f;     // + 2^-10 (zmax + enmax)
+    {
+      const float sroot = sqrtf(zbm) + sqrtf(enmax);
+      const float tv = (sroot * sroot + Cb) * thr_rel;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) thr[t] = tv;
+    }
     for (int c = 0; c < nchunks; ++c) {
-      if (filled_chunk != c) {
+      {
         __syncthreads();
         const int kbase = c * Kc;
-        copy_frags_lds<T>(wl, pk + (size_t)(kbase / 16) * NF * 64, (Kc / 16) * NF * 64, tid, 256);
-        for (int i = tid; i < Kc; i += 256) enl[i] = (kbase + i < K) ? en_g[kbase + i] : 3.0e38f;
+        if (filled_chunk != c) copy_frags_lds<T>(wl, pk + (size_t)(kbase / 16) * NF * 64, (Kc / 16) * NF * 64, tid, 256);
+        for (int i = tid; i < Kc; i += 256) enl[i] = (kbase + i < K) ? en_g[kbase + i] + Cb : 3.0e38f;
         __syncthreads();
         filled_chunk = c;
       }
-      unsigned c1[NT], c2[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) { c1[t] = 0xFFFFFFFFu; c2[t] = 0xFFFFFFFFu; }
       const int nmb = Kc / 16;
-      for (int mb = 0; mb < nmb; ++mb) {
-        const f32x4 en4 = *reinterpret_cast<const f32x4*>(enl + mb * 16 + 4 * kc);
-        frag_t a[NF];
+      for (int g0 = 0; g0 < nmb; g0 += 8) {
+        unsigned c1[NT], c2[NT];
 #pragma unroll
-        for (int s = 0; s < NF; ++s) a[s] = wl[(mb * NF + s) * 64 + lane];
-        const unsigned lidx = (unsigned)(mb * 16 + 4 * kc);
+        for (int t = 0; t < NT; ++t) { c1[t] = 0xFFFFFFFFu; c2[t] = 0xFFFFFFFFu; }
+        const int g1e = (g0 + 8) < nmb ? (g0 + 8) : nmb;
+        for (int mb = g0; mb < g1e; ++mb) {
+          const f32x4 en4 = *reinterpret_cast<const f32x4*>(enl + mb * 16 + 4 * kc);
+          frag_t a[NF];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          f32x4 acc = {en4[0] + biasv[t], en4[1] + biasv[t], en4[2] + biasv[t], en4[3] + biasv[t]};
+          for (int s = 0; s < NF; ++s) a[s] = wl[(mb * NF + s) * 64 + lane];
+          const unsigned lidx = (unsigned)((mb - g0) * 16 + 4 * kc);
 #pragma unroll
-          for (int s = 0; s < NF; ++s) acc = mfma16(a[s], zt[t].f[s], acc);
+          for (int t = 0; t < NT; ++t) {
+            f32x4 acc = en4;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const unsigned key = (__float_as_uint(acc[r]) & ~VQ_IDX_MASK) | (lidx + r);
-            { const unsigned mx = c1[t] > key ? c1[t] : key; c2[t] = c2[t] < mx ? c2[t] : mx; }
-            c1[t] = c1[t] < key ? c1[t] : key;
+            for (int s = 0; s < NF; ++s) acc = mfma16(a[s], zt[t].f[s], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const unsigned key = (__float_as_uint(acc[r]) & ~VQ_IDX_MASK) | (lidx + r);
+              asm("v_med3_u32 %0, %1, %2, %3" : "=v"(c2[t]) : "v"(c1[t]), "v"(c2[t]), "v"(key));   // runner-up (c1 <= c2)
+              c1[t] = c1[t] < key ? c1[t] : key;
+            }
           }
         }
-      }
+        const int gid = c * (Kc / 16) + g0;                     // group base in units of 16 codes
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const unsigned hi = g1[t] > c1[t] ? g1[t] : c1[t];
-        const unsigned lo2 = g2[t] < c2[t] ? g2[t] : c2[t];
-        g2[t] = hi < lo2 ? hi : lo2;
-        if (c1[t] < g1[t]) { g1[t] = c1[t]; gc[t] = c; }
+        for (int t = 0; t < NT; ++t) {
+          const unsigned hi = g1[t] > c1[t] ? g1[t] : c1[t];
+          const unsigned lo2 = g2[t] < c2[t] ? g2[t] : c2[t];
+          g2[t] = hi < lo2 ? hi : lo2;
+          if (c1[t] < g1[t]) { g1[t] = c1[t]; gc[t] = gid; }
+        }
       }
     }
     // ---- wave-level min-reduce over the 4 lane groups that share a vector ----
@@ -179,7 +199,7 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(
         if (o1 < g1[t] || (o1 == g1[t] && oc < gc[t])) { g1[t] = o1; gc[t] = oc; }
       }
       const int64_t row = v0 + t * 16 + vx;
-      const int code = gc[t] * Kc + (int)(g1[t] & VQ_IDX_MASK);
+      const int code = gc[t] * 16 + (int)(g1[t] & VQ_IDX_MASK);
       const float s1 = __uint_as_float(g1[t] & ~VQ_IDX_MASK), s2 = __uint_as_float(g2[t] & ~VQ_IDX_MASK);
       const bool amb = !((s2 - s1) > thr[t]);   // also catches NaN
       if (row < N) {
@@ -309,27 +329,21 @@ __global__ __launch_bounds__(256) void vq_fixup_lds_kernel(const T* __restrict__
                                                            const int32_t* __restrict__ amb_list, VqHeader* __restrict__ hdr,
                                                            int32_t* __restrict__ idx_out, T* __restrict__ zq_out,
                                                            int32_t* __restrict__ counts_fix) {
+  // requires d % 4 == 0: rows are 16-byte aligned (pitch d + 4 floats -> conflict-free ds_read_b128 across lanes)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pitch = d + 1;
+  const int pitch = d + 4, d4 = d >> 2;
   float* et = reinterpret_cast<float*>(smem);               // [K][pitch]
   float* zrow = et + (size_t)K * pitch + (size_t)wave * d;  // [4][d]
   const int namb = hdr->namb;
   if ((int)blockIdx.x * 4 >= namb) return;                  // whole workgroup has no rows: skip the fill
-  if ((d & 3) == 0) {
+  {
     const f32x4* E4 = reinterpret_cast<const f32x4*>(E);
-    const int d4 = d >> 2;
     for (int i = tid; i < K * d4; i += 256) {
       const int kk = i / d4, j = (i - kk * d4) * 4;
       const f32x4 v = E4[i];
-      float* dst = et + kk * pitch + j;
-      dst[0] = to_f32(from_f32<T>(v[0])); dst[1] = to_f32(from_f32<T>(v[1]));
-      dst[2] = to_f32(from_f32<T>(v[2])); dst[3] = to_f32(from_f32<T>(v[3]));
-    }
-  } else {
-    for (int i = tid; i < K * d; i += 256) {
-      const int kk = i / d, j = i - kk * d;
-      et[kk * pitch + j] = to_f32(from_f32<T>(E[i]));
+      *reinterpret_cast<f32x4*>(et + kk * pitch + j) =
+          f32x4{to_f32(from_f32<T>(v[0])), to_f32(from_f32<T>(v[1])), to_f32(from_f32<T>(v[2])), to_f32(from_f32<T>(v[3]))};
     }
   }
   __syncthreads();
@@ -341,20 +355,28 @@ __global__ __launch_bounds__(256) void vq_fixup_lds_kernel(const T* __restrict__
     for (int j = lane; j < d; j += 64) zrow[j] = to_f32(Z[n * (int64_t)d + j]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    const f32x4* z4 = reinterpret_cast<const f32x4*>(zrow);
     float m32 = 3.0e38f;
     double best = 1.0e300;
     int bestk = 0x7fffffff;
     for (int k0 = 0; k0 < K; k0 += 64) {
       const int k = k0 + lane;
-      const float* er = et + (k < K ? k : K - 1) * pitch;
-      float s = 0.f;
-      for (int j = 0; j < d; ++j) { const float df = zrow[j] - er[j]; s = fmaf(df, df, s); }
+      const f32x4* e4 = reinterpret_cast<const f32x4*>(et + (size_t)(k < K ? k : K - 1) * pitch);
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+      for (int j = 0; j < d4; ++j) {
+        const f32x4 zv = z4[j], ev = e4[j];
+        const float a0 = zv[0] - ev[0], a1 = zv[1] - ev[1], a2 = zv[2] - ev[2], a3 = zv[3] - ev[3];
+        s0 = fmaf(a0, a0, s0); s1 = fmaf(a1, a1, s1); s2 = fmaf(a2, a2, s2); s3 = fmaf(a3, a3, s3);
+      }
+      float s = (s0 + s1) + (s2 + s3);
       if (k >= K) s = 3.0e38f;
       float cm = s;
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) cm = fminf(cm, __shfl_xor(cm, off, 64));
       m32 = fminf(m32, cm);
       if (s <= m32 * (1.f + slack) + 1e-30f) {
+        const float* er = et + (size_t)k * pitch;
         double sd = 0.0;
         for (int j = 0; j < d; ++j) { const double df = (double)zrow[j] - (double)er[j]; sd += df * df; }
         if (sd < best) { best = sd; bestk = k; }
@@ -367,7 +389,7 @@ __global__ __launch_bounds__(256) void vq_fixup_lds_kernel(const T* __restrict__
       if (ob < best || (ob == best && ok < bestk)) { best = ob; bestk = ok; }
     }
     float sq = 0.f;
-    const float* eb = et + bestk * pitch;
+    const float* eb = et + (size_t)bestk * pitch;
     for (int j = lane; j < d; j += 64) {
       const float ev = eb[j];
       zq_out[n * (int64_t)d + j] = from_f32<T>(ev);
@@ -501,7 +523,8 @@ __global__ __launch_bounds__(256) void vq_bwd_kernel(const T* __restrict__ gout,
 // codebook are an outer loop (z is re-read once per chunk; one chunk covers K <= 512 at d <= 64).
 // ---------------------------------------------------------------------------------------------
 template <int RB, int CB>
-__global__ __launch_bounds__(256) void vq_bwd_mfma_kernel(const bf16* __restrict__ gout, const bf16* __restrict__ Z, const float* __restrict__ E,
+__global__ __launch_bounds__(256) void vq_bwd_mfma_kernel(const bf16* __restrict__ gout, const bf16* __restrict__ Z, const bf16* __restrict__ ZQ,
+                                                          const float* __restrict__ E,
                                                           const int32_t* __restrict__ idx, const float* __restrict__ gscale, float cz_base,
                                                           int64_t N, int K, int d, int64_t rows_per_wg, bf16* __restrict__ gz,
                                                           float* __restrict__ slab /*[grid][K][d]*/) {
@@ -551,11 +574,14 @@ __global__ __launch_bounds__(256) void vq_bwd_mfma_kernel(const bf16* __restrict
                 for (int e = 0; e < 8; ++e) if (c0 + e < d) gv[e] = (float)gout[n * (int64_t)d + c0 + e];
               }
             }
+            float qv[8];
+            if (ZQ != nullptr && fast) Vec<bf16>::load(ZQ + n * (int64_t)d + c0, qv);     // coalesced z_q instead of a codebook gather
+            else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float ev = (c0 + e < d) ? (float)(bf16)E[(int64_t)k * d + c0 + e] : 0.f;
-              ov[e] = gv[e] + cz * (zv[e] - ev);
+              for (int e = 0; e < 8; ++e) qv[e] = (c0 + e < d) ? (float)(bf16)E[(int64_t)k * d + c0 + e] : 0.f;
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = gv[e] + cz * (zv[e] - qv[e]);
             if (fast) Vec<bf16>::store(gz + n * (int64_t)d + c0, ov);
             else {
 #pragma unroll
@@ -622,6 +648,18 @@ __global__ void vq_code_reduce_kernel(const float* __restrict__ slab, int nslab,
     gE[i] = ce * ((float)counts[i / d] * ev - s);
   }
 }
+
+struct CodeEpi {
+  const float* E; const int32_t* counts; const float* gscale; float ce_base; int d, bf; float* gE; float* sums_out;
+  __device__ void operator()(int64_t i, float s) const {
+    if (sums_out) sums_out[i] = s;
+    if (gE) {
+      const float ce = ce_base * (gscale ? gscale[1] : 1.f);
+      const float ev = bf ? (float)(bf16)E[i] : E[i];
+      gE[i] = ce * ((float)counts[i / d] * ev - s);
+    }
+  }
+};
 
 // EMA update (scripts/train_vqvae.py:412-414): N_k, m_k moving averages + Laplace-smoothed codebook
 __global__ __launch_bounds__(256) void vq_ema_kernel(const float* __restrict__ sums, const int32_t* __restrict__ counts, int K, int d,
@@ -696,7 +734,7 @@ static int launch_vq(const void* z, const float* E, int64_t N, int K, int d, int
   const int npk = (kpadc / 16) * NF * 64;
   frag_t* pk = (frag_t*)(ws + L.pack);
   FRL_LAUNCH((vq_pack_kernel<T, NF>), dim3((npk + 255) / 256), dim3(256), 0, st, E, K, d, pk, npk);
-  const size_t lds = (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc * 4 + (size_t)K * 4;
+  const size_t lds = (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc * 4 + (size_t)K * 4 + 16;
   if (lds > 160 * 1024) return frl_fail(-3, "vq_assign: LDS budget exceeded (K too large for histogram)");
   auto kern = vq_assign_kernel<T, NF, VQ_NT>;
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -707,8 +745,8 @@ static int launch_vq(const void* z, const float* E, int64_t N, int K, int d, int
     auto fk = vq_fixup_kernel<T>;
     if (fix_lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fix_lds));
   }
-  const size_t res_lds = ((size_t)K * (d + 1) + 4 * (size_t)d) * sizeof(float);
-  if (res_lds <= 150 * 1024) {
+  const size_t res_lds = ((size_t)K * (d + 4) + 4 * (size_t)d) * sizeof(float);
+  if (res_lds <= 150 * 1024 && (d & 3) == 0) {
     auto fk = vq_fixup_lds_kernel<T>;
     if (res_lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds));
     FRL_LAUNCH(fk, dim3(128), dim3(256), res_lds, st, (const T*)z, E, K, d, (const int32_t*)(ws + L.amb), hdr, idx, (T*)zq,
@@ -763,9 +801,10 @@ int frl_vq_assign_fwd(const void* z, const float* E, int64_t N, int K, int d, in
 }
 
 // g_z = g_out + gscale[0] * beta * 2/(N d) * (z - e_idx);  g_E[k] = gscale[1] * 2/(N d) * (n_k e_k - sum_{idx=k} z)
-// gscale: device float[2] = upstream gradients of {L_commit, L_codebook}, may be null (= {1, 1}).  g_out may be null (=0).
+// gscale: device float[2] = upstream gradients of {L_commit, L_codebook}, may be null (= {1, 1}).
+// zq (optional): the forward's z_q rows; when given the bf16 path reads it instead of gathering codebook rows.  g_out may be null (=0).
 // g_z / g_E may be null to skip.  sums_out (optional, [K][d] f32) receives the per-code sums of z.
-int frl_vq_bwd(const void* g_out, const void* z, const float* E, const int32_t* idx, const int32_t* counts,
+int frl_vq_bwd(const void* g_out, const void* z, const void* zq, const float* E, const int32_t* idx, const int32_t* counts,
                const float* gscale, float beta, int64_t N, int K, int d, void* g_z_out, float* g_E_out,
                float* sums_out, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (N <= 0) return frl_fail(-2, "vq_bwd: empty input");
@@ -780,22 +819,20 @@ int frl_vq_bwd(const void* g_out, const void* z, const float* E, const int32_t* 
     if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     FRL_LAUNCH(kern, dim3(VQ_BWD_WGS), dim3(256), lds, stream, (const float*)g_out, (const float*)z, E, idx, gscale,
                        cz, N, K, d, Kc, rows, (float*)g_z_out, slab);
-    FRL_LAUNCH((vq_code_reduce_kernel<float>), dim3((unsigned)(((int64_t)K * d + 255) / 256)), dim3(256), 0, stream,
-                       (const float*)slab, VQ_BWD_WGS, E, counts, gscale, ce, K, d, g_E_out, sums_out);
+    launch_slab_reduce<float, CodeEpi>((const float*)slab, VQ_BWD_WGS, (int64_t)K * d, CodeEpi{E, counts, gscale, ce, d, 0, g_E_out, sums_out}, stream);
   } else if (dtype == FRL_BF16) {
     const int64_t rows64 = (rows + 63) / 64 * 64;
     if (d <= 32) {
-      FRL_LAUNCH((vq_bwd_mfma_kernel<8, 2>), dim3(VQ_BWD_WGS), dim3(256), (size_t)64 * 40 * 2 + 256, stream, (const bf16*)g_out, (const bf16*)z, E, idx,
+      FRL_LAUNCH((vq_bwd_mfma_kernel<8, 2>), dim3(VQ_BWD_WGS), dim3(256), (size_t)64 * 40 * 2 + 256, stream, (const bf16*)g_out, (const bf16*)z, (const bf16*)zq, E, idx,
                  gscale, cz, N, K, d, rows64, (bf16*)g_z_out, slab);
     } else if (d <= 64) {
-      FRL_LAUNCH((vq_bwd_mfma_kernel<8, 4>), dim3(VQ_BWD_WGS), dim3(256), (size_t)64 * 72 * 2 + 256, stream, (const bf16*)g_out, (const bf16*)z, E, idx,
+      FRL_LAUNCH((vq_bwd_mfma_kernel<8, 4>), dim3(VQ_BWD_WGS), dim3(256), (size_t)64 * 72 * 2 + 256, stream, (const bf16*)g_out, (const bf16*)z, (const bf16*)zq, E, idx,
                  gscale, cz, N, K, d, rows64, (bf16*)g_z_out, slab);
     } else {
-      FRL_LAUNCH((vq_bwd_mfma_kernel<4, 8>), dim3(VQ_BWD_WGS), dim3(256), (size_t)64 * 136 * 2 + 256, stream, (const bf16*)g_out, (const bf16*)z, E, idx,
+      FRL_LAUNCH((vq_bwd_mfma_kernel<4, 8>), dim3(VQ_BWD_WGS), dim3(256), (size_t)64 * 136 * 2 + 256, stream, (const bf16*)g_out, (const bf16*)z, (const bf16*)zq, E, idx,
                  gscale, cz, N, K, d, rows64, (bf16*)g_z_out, slab);
     }
-    FRL_LAUNCH((vq_code_reduce_kernel<bf16>), dim3((unsigned)(((int64_t)K * d + 255) / 256)), dim3(256), 0, stream,
-                       (const float*)slab, VQ_BWD_WGS, E, counts, gscale, ce, K, d, g_E_out, sums_out);
+    launch_slab_reduce<float, CodeEpi>((const float*)slab, VQ_BWD_WGS, (int64_t)K * d, CodeEpi{E, counts, gscale, ce, d, 1, g_E_out, sums_out}, stream);
   } else return frl_fail(-2, "vq_bwd: bad dtype");
   return frl_check_launch("vq_bwd");
 }

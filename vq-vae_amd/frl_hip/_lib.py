@@ -36,7 +36,7 @@ SIGNATURES = {
     "frl_conv_tap_bwd_weight": (c_int, [P, P, I, P, P, L, L, P, L, I, I, I, I, I, I, P, S, I, P]),
     "frl_vq_workspace_bytes": (S, [L, I, I]),
     "frl_vq_assign_fwd": (c_int, [P, P, L, I, I, P, P, P, P, I, P, S, P]),
-    "frl_vq_bwd": (c_int, [P, P, P, P, P, P, F, L, I, I, P, P, P, I, P, S, P]),
+    "frl_vq_bwd": (c_int, [P, P, P, P, P, P, P, F, L, I, I, P, P, P, I, P, S, P]),
     "frl_vq_ema_update": (c_int, [P, P, I, I, F, F, P, P, P, P]),
     "frl_groupnorm_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, F, I, I, P]),
     "frl_groupnorm_bwd_workspace_bytes": (S, [I, I, I]),

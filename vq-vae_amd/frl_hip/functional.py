@@ -186,7 +186,7 @@ class VQFn(Function):
         d = z.shape[-1]
         n = z.numel() // d
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(z, codebook, idx, counts)
+        ctx.save_for_backward(z, codebook, idx, counts, zq)
         mse = stats[0] / float(n * d)
         ctx.mark_non_differentiable(idx, counts)
         return zq, mse, mse.clone(), stats[1].clone(), idx, counts
@@ -194,14 +194,14 @@ class VQFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g_zq, g_cb, g_cm, g_perp, g_idx, g_counts):
-        z, codebook, idx, counts = ctx.saved_tensors
+        z, codebook, idx, counts, zq = ctx.saved_tensors
         gs = torch.zeros(2, dtype=torch.float32, device=z.device)
         if g_cm is not None:
             gs[0] = g_cm
         if g_cb is not None:
             gs[1] = g_cb
         gz, ge, _ = ops.vq_bwd(_c(g_zq), z, codebook, idx, counts, gs, 1.0,
-                               want_gz=ctx.needs_input_grad[0], want_ge=ctx.needs_input_grad[1])
+                               want_gz=ctx.needs_input_grad[0], want_ge=ctx.needs_input_grad[1], zq=zq)
         return gz, ge
 
 

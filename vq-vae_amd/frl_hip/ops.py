@@ -184,7 +184,7 @@ def vq_assign(z: torch.Tensor, codebook: torch.Tensor):
 @_timed("vq_bwd")
 def vq_bwd(g_out: Optional[torch.Tensor], z: torch.Tensor, codebook: torch.Tensor, idx: torch.Tensor,
            counts: torch.Tensor, gscale: Optional[torch.Tensor], beta: float, want_gz: bool = True,
-           want_ge: bool = True, want_sums: bool = False):
+           want_ge: bool = True, want_sums: bool = False, zq: Optional[torch.Tensor] = None):
     k, d = codebook.shape
     n = z.numel() // d
     lib = _lib.load()
@@ -192,7 +192,7 @@ def vq_bwd(g_out: Optional[torch.Tensor], z: torch.Tensor, codebook: torch.Tenso
     gz = torch.empty_like(z) if want_gz else None
     ge = torch.empty(k, d, dtype=torch.float32, device=z.device) if want_ge else None
     sums = torch.empty(k, d, dtype=torch.float32, device=z.device) if want_sums else None
-    check(lib.frl_vq_bwd(_p(g_out), _p(z), _p(_f32(codebook, "codebook")), _p(idx), _p(counts), _p(gscale), float(beta),
+    check(lib.frl_vq_bwd(_p(g_out), _p(z), _p(zq), _p(_f32(codebook, "codebook")), _p(idx), _p(counts), _p(gscale), float(beta),
                          n, k, d, _p(gz), _p(ge), _p(sums), _dt(z), _p(ws), ws.numel(), _stream()), "frl_vq_bwd")
     return gz, ge, sums
 
