@@ -119,6 +119,20 @@ int frl_tcn_block_bwd_fused(const void* x, const void* dy, const float* conv_w, 
                             float* d_conv_b, float* d_gn_w, float* d_gn_b, float* d_gate_w, float* d_gate_b, int64_t npix,
                             int HW, int T, int dilation, int G, float eps, void* ws, size_t ws_bytes, frl_stream_t stream);
 
+/* hot-configuration block kernels (bf16, Cin = Cout = 64, T = 5, G = 8, identity residual, dilation 1/2/4: the three phase-path
+ * blocks of configs/vae_v0.yaml): (T, dilation) are compile-time, the pixel's time series stays in registers, the temporal
+ * conv is evaluated once per tile.  frl_tcn_hot_bwd is one launch for dx + every parameter gradient (tcn.py:78-111). */
+int frl_tcn_hot_supported(int T, int Cin, int Cout, int G, int dilation, int has_proj, int dtype);
+size_t frl_tcn_hot_fwd_workspace_bytes(void);
+size_t frl_tcn_hot_bwd_workspace_bytes(int64_t npix);
+int frl_tcn_hot_fwd(const void* x, const float* conv_w, const float* conv_b, const float* gn_w, const float* gn_b,
+                    const float* gate_w, const float* gate_b, void* y, int64_t npix, int HW, int dilation, float eps, void* ws,
+                    size_t ws_bytes, frl_stream_t stream);
+int frl_tcn_hot_bwd(const void* x, const void* dy, const float* conv_w, const float* conv_b, const float* gn_w,
+                    const float* gn_b, const float* gate_w, const float* gate_b, void* dx, float* d_conv_w, float* d_conv_b,
+                    float* d_gn_w, float* d_gn_b, float* d_gate_w, float* d_gate_b, int64_t npix, int HW, int dilation,
+                    float eps, void* ws, size_t ws_bytes, frl_stream_t stream);
+
 /* ---- FiLM modulation, time mean, add ---------------------------------------------------------------------------
  * z = gamma * h + beta broadcast over T (frl/models/representation.py:369-372); h [B][T][HW][C], gamma [B][HW][C]. */
 int frl_film_modulate_fwd(const void* h, const void* gamma, const void* beta, void* out, int64_t B, int T, int64_t HW,

@@ -257,6 +257,41 @@ def test_tcn_block_bwd_fused_matches_oracle_and_unfused(B, T, HW, dil):
         assert rel_err(fused[kk].reshape(ref.shape), unf[kk].reshape(ref.shape).cpu()) <= 0.03, kk
 
 
+@pytest.mark.parametrize("B,HW,dil", [(1, 1024, 1), (2, 1024, 2), (3, 100, 4), (1, 77, 2), (5, 13, 1), (1, 16, 4)])
+def test_tcn_hot_kernels_match_oracle_and_generic(B, HW, dil):
+    """The (T=5, dilation)-specialised bf16 block kernels vs float64 autograd and vs the generic kernels (ragged pixel counts too)."""
+    from frl_hip import ops, _lib
+    dtype, cin, cout, G, T = torch.bfloat16, 64, 64, 8, 5
+    assert _lib.load().frl_tcn_hot_supported(T, cin, cout, G, dil, 0, 1) == 1
+    assert _lib.load().frl_tcn_hot_supported(T, cin, cout, G, 3, 0, 1) == 0 and _lib.load().frl_tcn_hot_supported(4, cin, cout, G, dil, 0, 1) == 0
+    g = torch.Generator().manual_seed(B * HW + dil)
+    p = "b."
+    st = {p + "conv.weight": torch.randn(cout, cin, 3, generator=g) / (3 * cin) ** 0.5, p + "conv.bias": torch.randn(cout, generator=g) * 0.1,
+          p + "norm.weight": torch.rand(cout, generator=g) + 0.5, p + "norm.bias": torch.randn(cout, generator=g) * 0.2,
+          p + "gate.weight": torch.randn(cout, cout, 1, generator=g) / cout ** 0.5, p + "gate.bias": torch.randn(cout, generator=g) * 0.1}
+    ref_st = {k: ((q(v, dtype) if k.endswith(("conv.weight", "gate.weight")) else v.double()).requires_grad_(True)) for k, v in st.items()}
+    x = q(torch.randn(B, T, HW, cin, generator=g), dtype).requires_grad_(True)
+    yr = O.tcn_block_forward(ref_st, x.permute(0, 2, 3, 1).reshape(B * HW, cin, T), dil, G, p).reshape(B, HW, cout, T).permute(0, 3, 1, 2)
+    dy = q(torch.randn(B, T, HW, cout, generator=g), dtype)
+    yr.backward(dy)
+    dev = {k: v.float().to(DEV) for k, v in st.items()}
+    args = (dev[p + "conv.weight"], dev[p + "conv.bias"], dev[p + "norm.weight"], dev[p + "norm.bias"], dev[p + "gate.weight"], dev[p + "gate.bias"], None, None)
+    xd, dyd = x.detach().to(dtype).to(DEV), dy.to(dtype).to(DEV)
+    y_hot = ops.tcn_block_fwd(xd, *args, dil, G)
+    y_gen = ops.tcn_block_fwd(xd, *args, dil, G, allow_hot=False)
+    assert rel_err(y_hot.float(), yr.detach()) <= 8e-3            # bf16 output rounding (2^-8 relative)
+    assert rel_err(y_hot.float(), y_gen.float().cpu()) <= 8e-3
+    hot = ops.tcn_block_bwd(xd, dyd, *args, dil, G)
+    gen = ops.tcn_block_bwd(xd, dyd, *args, dil, G, allow_hot=False)
+    assert rel_err(hot["dx"].float(), x.grad) <= 2e-2
+    assert rel_err(hot["dx"].float(), gen["dx"].float().cpu()) <= 3e-2
+    names = dict(conv_w="conv.weight", conv_b="conv.bias", gn_w="norm.weight", gn_b="norm.bias", gate_w="gate.weight", gate_b="gate.bias")
+    for kk, nm in names.items():
+        ref = ref_st[p + nm].grad
+        assert rel_err(hot[kk].reshape(ref.shape), ref) <= 2e-2, kk
+        assert rel_err(hot[kk].reshape(ref.shape), gen[kk].reshape(ref.shape).cpu()) <= 2e-2, kk
+
+
 @pytest.mark.parametrize("P,cz,use_mask", [(4096, 64, False), (5000, 12, True), (333, 12, False), (1000, 32, True), (130, 64, True)])
 def test_fused_decoder_mse(P, cz, use_mask):
     """Fused decoder + L2 loss (bf16) vs float64 autograd of the same chain, and vs the modular kernels."""

@@ -1,0 +1,552 @@
+// Hot-configuration GatedResidualBlock kernels (frl/models/tcn.py:78-111): bf16, Cin = Cout = 64, T = 5, 8-channel GroupNorm
+// groups, identity residual, dilation 1 / 2 / 4 -- the three blocks of the phase path at BASELINE configs[1..3].
+//
+// Everything that depends on (T, dilation) is a template constant, so the whole per-pixel time series lives in registers
+// with static indexing (no scratch, no select chains): a wave owns 16 pixels for all 5 time steps in the lane-quarter image
+// (frl_common.hpp).  The temporal convolution is computed ONCE per tile into 20 accumulator tiles (5 t x 4 channel blocks),
+// each weight fragment is fetched from LDS once and reused for every time step it applies to, the GroupNorm statistics are an
+// exact two-pass in-lane reduction over those accumulators, and the gate GEMM / sigmoid / blend read them in place.
+//
+//   forward : y = g * relu(n) + (1 - g) * x,  n = GN(conv(x) + b),  g = sigmoid(Wg n + bg)          (x read, y written: 2 x 128 B / (px,t))
+//   backward: ONE launch -> dx + every parameter gradient.  Per 64-pixel workgroup tile:
+//     P1 (per wave, no barrier)  recompute conv/GN/gate, dgpre, dres, dn, GroupNorm backward -> dconv, dx = conv^T(dconv) + dres
+//                                (stored), publish bf16 images of n[t], dgpre[t] for all t into LDS
+//     P2 gate weight gradient    dWg += dgpre^T n   (contraction over the 64 pixels x 5 t; operands via ds_read_b64_tr_b16)
+//     P3 publish dconv[t], x[t]  into the same LDS tiles
+//     P4 conv weight gradient    dW_k += dconv[t]^T x[t + (k-1) d]
+//   Four barriers per tile; wave w owns rows [16w, 16w+16) of the four 64x64 gradient matrices in registers for the whole
+//   kernel; per-workgroup float32 slabs are summed in a fixed order afterwards (bit-reproducible, no float atomics).
+#include "tcn_common.hpp"
+#include "frl_host.hpp"
+#include "frl_reduce.hpp"
+
+#define TH_T 5
+#define TH_PITCH 72       // bf16 elements per pixel row in LDS tiles (64 + 8: conflict-free 16-byte writes and tr16 reads)
+
+typedef bf16x8 frag8;
+struct Tile2 { frag8 f[2]; };
+
+template <int DIL> __device__ __forceinline__ constexpr bool th_valid(int t, int k) {
+  return t + (k - 1) * DIL >= 0 && t + (k - 1) * DIL < TH_T;
+}
+
+__device__ __forceinline__ float th_elem(const Tile2& t, int j) { return (float)t.f[j >> 3][j & 7]; }
+
+__device__ __forceinline__ Tile2 th_pack(const float (&v)[16]) {
+  Tile2 o;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) o.f[j >> 3][j & 7] = (bf16)v[j];
+  return o;
+}
+
+// conv for all time steps: acc[t][m] (+)= sum_k W_k x[t + (k-1) DIL]; each weight fragment is read from LDS once
+template <int DIL>
+__device__ __forceinline__ void th_conv(f32x4 (&acc)[TH_T][4], const Tile2 (&x)[TH_T], const frag8* __restrict__ wl, int lane) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const frag8 wf = wl[((k * 4 + m) * 2 + s) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < TH_T; ++t)
+          if (th_valid<DIL>(t, k)) acc[t][m] = mfma16(wf, x[t + (k - 1) * DIL].f[s], acc[t][m]);
+      }
+}
+
+// exact two-pass GroupNorm statistics of the lane's two 8-channel groups over (8 ch x 5 t); acc already holds conv + bias
+__device__ __forceinline__ void th_stats(const f32x4 (&acc)[TH_T][4], float eps, float (&mean)[2], float (&rstd)[2]) {
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < TH_T; ++t)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += acc[t][2 * g + m][r];
+    const float mu = s * (1.f / 40.f);
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < TH_T; ++t)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = acc[t][2 * g + m][r] - mu; q = fmaf(d, d, q); }
+    mean[g] = mu;
+    rstd[g] = 1.f / sqrtf(q * (1.f / 40.f) + eps);
+  }
+}
+
+__device__ __forceinline__ Tile2 th_load(const bf16* __restrict__ p) {
+  Tile2 t;
+  t.f[0] = *reinterpret_cast<const frag8*>(p);
+  t.f[1] = *reinterpret_cast<const frag8*>(p + 8);
+  return t;
+}
+__device__ __forceinline__ void th_store(bf16* __restrict__ p, const Tile2& t) {
+  *reinterpret_cast<frag8*>(p) = t.f[0];
+  *reinterpret_cast<frag8*>(p + 8) = t.f[1];
+}
+
+// =============================================================================================================
+// forward
+// =============================================================================================================
+template <int DIL>
+__global__ __launch_bounds__(256, 2) void tcn_hot_fwd_kernel(const bf16* __restrict__ X, const frag8* __restrict__ Wpk,
+                                                             const float* __restrict__ bc, const float* __restrict__ gn_w,
+                                                             const float* __restrict__ gn_b, const float* __restrict__ bg,
+                                                             bf16* __restrict__ Y, int64_t npix, int HW, float eps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  frag8* wl_conv = reinterpret_cast<frag8*>(smem);                 // [3][4][2][64]
+  frag8* wl_gate = wl_conv + 24 * 64;                              // [4][2][64]
+  float* tab = reinterpret_cast<float*>(wl_gate + 8 * 64);         // conv bias | gamma | beta | -log2e * gate bias
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, kc = lane >> 4;
+  copy_frags_lds<bf16>(wl_conv, Wpk, 32 * 64, tid, 256);
+  if (tid < 64) {
+    tab[tid] = bc[tid];
+    tab[64 + tid] = gn_w[tid];
+    tab[128 + tid] = gn_b[tid];
+    tab[192 + tid] = -1.44269504088896f * bg[tid];
+  }
+  __syncthreads();
+  const f32x4* tcb = reinterpret_cast<const f32x4*>(tab + 16 * kc);
+  const float* tgw = tab + 64 + 16 * kc;
+  const float* tgb = tab + 128 + 16 * kc;
+  const float* tnbg = tab + 192 + 16 * kc;
+
+  const int64_t ntile = (npix + 15) >> 4;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
+    int64_t pidx = tile * 16 + px;
+    const bool valid = pidx < npix;
+    if (!valid) pidx = npix - 1;
+    const int64_t b = pidx / HW, hw = pidx % HW;
+    const int64_t row0 = b * TH_T * HW + hw;
+    const bf16* xp = X + row0 * 64 + 16 * kc;
+    Tile2 x[TH_T];
+#pragma unroll
+    for (int t = 0; t < TH_T; ++t) x[t] = th_load(xp + (int64_t)t * HW * 64);
+    f32x4 acc[TH_T][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 cb = tcb[m];
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t) acc[t][m] = cb;
+    }
+    th_conv<DIL>(acc, x, wl_conv, lane);
+    float mean[2], rstd[2];
+    th_stats(acc, eps, mean, rstd);
+    const float nm[2] = {-mean[0] * rstd[0], -mean[1] * rstd[1]};  // xhat = acc * rstd + nm
+    bf16* yp = Y + row0 * 64 + 16 * kc;
+#pragma unroll
+    for (int t = 0; t < TH_T; ++t) {
+      __builtin_amdgcn_sched_barrier(0);
+      float n[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) n[j] = fmaf(fmaf(acc[t][j >> 2][j & 3], rstd[j >> 3], nm[j >> 3]), tgw[j], tgb[j]);
+      const Tile2 nt = th_pack(n);
+      f32x4 gacc[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        gacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) gacc[m] = mfma16(wl_gate[(m * 2 + s) * 64 + lane], nt.f[s], gacc[m]);
+      }
+      float y[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float g = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(gacc[j >> 2][j & 3], -1.44269504088896f, tnbg[j])));
+        const float o = fmaxf(n[j], 0.f);
+        const float res = th_elem(x[t], j);
+        y[j] = fmaf(g, o - res, res);
+      }
+      if (valid) th_store(yp + (int64_t)t * HW * 64, th_pack(y));
+    }
+  }
+}
+
+// =============================================================================================================
+// backward
+// =============================================================================================================
+// k-strided MFMA fragment (8 consecutive pixels of one channel) from a [pixel][TH_PITCH] LDS tile
+__device__ __forceinline__ frag8 th_tr(const bf16* tile, int pix0, int ch0, int r16) {
+  const bf16* a0 = tile + (pix0 + (r16 >> 2)) * TH_PITCH + ch0 + 4 * (r16 & 3);
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0 + 4 * TH_PITCH));
+  return frag8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ void th_put(bf16* tile, int prow, int kc, const Tile2& t) {
+  frag8* p = reinterpret_cast<frag8*>(tile + prow * TH_PITCH + 16 * kc);
+  p[0] = t.f[0];
+  p[1] = t.f[1];
+}
+
+// slab layout per workgroup (floats): [3][64][64] conv taps | [64][64] gate | [64] dbc | [64] dbg | [64] dgamma | [64] dbeta
+#define TH_SLAB (4 * 64 * 64 + 4 * 64)
+#define TH_TILE (64 * TH_PITCH)
+
+template <int DIL>
+__global__ __launch_bounds__(256) void tcn_hot_bwd_kernel(const bf16* __restrict__ X, const bf16* __restrict__ DY,
+                                                          const frag8* __restrict__ Wpk, const float* __restrict__ bc,
+                                                          const float* __restrict__ gn_w, const float* __restrict__ gn_b,
+                                                          const float* __restrict__ bg, bf16* __restrict__ DX, float* __restrict__ slab,
+                                                          int64_t npix, int HW, float eps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  frag8* wl_conv = reinterpret_cast<frag8*>(smem);               // [3][4][2][64]
+  frag8* wl_gate = wl_conv + 24 * 64;                            // [4][2][64]
+  frag8* wl_gateT = wl_gate + 8 * 64;                            // [4][2][64]
+  frag8* wl_convT = wl_gateT + 8 * 64;                           // [3][4][2][64]
+  float* tab = reinterpret_cast<float*>(wl_convT + 24 * 64);     // conv bias | gamma | beta | -log2e * gate bias
+  float* gacc_lds = tab + 4 * 64;                                // [4 waves][2][64]
+  bf16* bufA = reinterpret_cast<bf16*>(gacc_lds + 4 * 2 * 64);   // [T][64 px][PITCH]  dgpre[t], later dconv[t]
+  bf16* bufB = bufA + TH_T * TH_TILE;                            // [T][64 px][PITCH]  n[t],     later x[t]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, kc = lane >> 4, r16 = px;
+  const int prow = wave * 16 + px;
+
+  copy_frags_lds<bf16>(wl_conv, Wpk, 64 * 64, tid, 256);
+  if (tid < 64) {
+    tab[tid] = bc[tid];
+    tab[64 + tid] = gn_w[tid];
+    tab[128 + tid] = gn_b[tid];
+    tab[192 + tid] = -1.44269504088896f * bg[tid];
+  }
+  __syncthreads();
+  const f32x4* tcb = reinterpret_cast<const f32x4*>(tab + 16 * kc);
+  const float* tgw = tab + 64 + 16 * kc;
+  const float* tgb = tab + 128 + 16 * kc;
+  const float* tnbg = tab + 192 + 16 * kc;
+
+  f32x4 accC[3][4], accG[4], accCb = {0.f, 0.f, 0.f, 0.f}, accGb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accC[k][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accG[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dgam[16], dbet[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { dgam[j] = 0.f; dbet[j] = 0.f; }
+  const frag8 ones = (r16 == 0) ? frag8{(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f}
+                                : frag8{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+
+  const int64_t nwt = (npix + 63) >> 6;
+  for (int64_t wt = blockIdx.x; wt < nwt; wt += gridDim.x) {
+    int64_t pidx = wt * 64 + prow;
+    const bool valid = pidx < npix;
+    if (!valid) pidx = npix - 1;
+    const int64_t b = pidx / HW, hw = pidx % HW;
+    const int64_t row0 = b * TH_T * HW + hw;
+    const bf16* xp = X + row0 * 64 + 16 * kc;
+    const bf16* dyp = DY + row0 * 64 + 16 * kc;
+    Tile2 x[TH_T];
+#pragma unroll
+    for (int t = 0; t < TH_T; ++t) x[t] = th_load(xp + (int64_t)t * HW * 64);
+    Tile2 dyc = th_load(dyp);                                      // dy[t] is fetched one time step ahead of its use
+    // ---------------- P1: per-pixel backward ----------------
+    f32x4 acc[TH_T][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 cb = tcb[m];
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t) acc[t][m] = cb;
+    }
+    th_conv<DIL>(acc, x, wl_conv, lane);
+    float mean[2], rstd[2];
+    th_stats(acc, eps, mean, rstd);
+    const float nm[2] = {-mean[0] * rstd[0], -mean[1] * rstd[1]};
+    float S1[2] = {0.f, 0.f}, S2[2] = {0.f, 0.f};
+    Tile2 dr[TH_T], dxh[TH_T];
+#pragma unroll
+    for (int t = 0; t < TH_T; ++t) {
+      __builtin_amdgcn_sched_barrier(0);
+      Tile2 dyt = dyc;
+      if (t + 1 < TH_T) dyc = th_load(dyp + (int64_t)(t + 1) * HW * 64);
+      if (!valid) { dyt.f[0] = frag8{}; dyt.f[1] = frag8{}; }     // clamped duplicate pixel: contributes nothing
+      float xh[16], n[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        xh[j] = fmaf(acc[t][j >> 2][j & 3], rstd[j >> 3], nm[j >> 3]);
+        acc[t][j >> 2][j & 3] = xh[j];                            // keep xhat for the GroupNorm backward
+        n[j] = fmaf(xh[j], tgw[j], tgb[j]);
+      }
+      const Tile2 nt = th_pack(n);
+      th_put(bufB + t * TH_TILE, prow, kc, nt);
+      f32x4 gacc[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        gacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) gacc[m] = mfma16(wl_gate[(m * 2 + s) * 64 + lane], nt.f[s], gacc[m]);
+      }
+      float dgp[16], drv[16];
+      f32x4 bacc[4];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float dyv = th_elem(dyt, j);
+        const float g = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(gacc[j >> 2][j & 3], -1.44269504088896f, tnbg[j])));
+        const float o = fmaxf(n[j], 0.f);
+        const float res = th_elem(x[t], j);
+        const float dyg = dyv * g;
+        drv[j] = dyv - dyg;                                        // dy (1 - g)
+        dgp[j] = (o - res) * (dyg - dyg * g);                      // dy (o - res) g (1 - g)
+        bacc[j >> 2][j & 3] = n[j] > 0.f ? dyg : 0.f;              // relu path of dn; Wg^T dgpre is accumulated on top
+      }
+      const Tile2 gt = th_pack(dgp);
+      th_put(bufA + t * TH_TILE, prow, kc, gt);
+      dr[t] = th_pack(drv);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) bacc[m] = mfma16(wl_gateT[(m * 2 + s) * 64 + lane], gt.f[s], bacc[m]);
+      float d[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float dnv = bacc[j >> 2][j & 3];
+        dgam[j] = fmaf(dnv, xh[j], dgam[j]);
+        dbet[j] += dnv;
+        d[j] = dnv * tgw[j];
+        S1[j >> 3] += d[j];
+        S2[j >> 3] = fmaf(d[j], xh[j], S2[j >> 3]);
+      }
+      dxh[t] = th_pack(d);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    Tile2 dct[TH_T];
+    {
+      const float m1[2] = {S1[0] * (1.f / 40.f), S1[1] * (1.f / 40.f)};
+      const float m2[2] = {S2[0] * (1.f / 40.f), S2[1] * (1.f / 40.f)};
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t) {
+        float dc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          dc[j] = rstd[j >> 3] * (th_elem(dxh[t], j) - m1[j >> 3] - acc[t][j >> 2][j & 3] * m2[j >> 3]);
+        dct[t] = th_pack(dc);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // dx[t'] = sum_k W_k^T dconv[t' - (k-1) d] + dres[t']   (accumulators initialised with dres)
+    {
+      f32x4 dxa[TH_T][4];
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          dxa[t][m] = f32x4{th_elem(dr[t], 4 * m), th_elem(dr[t], 4 * m + 1), th_elem(dr[t], 4 * m + 2), th_elem(dr[t], 4 * m + 3)};
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const frag8 wf = wl_convT[((k * 4 + m) * 2 + s) * 64 + lane];
+#pragma unroll
+            for (int tp = 0; tp < TH_T; ++tp)
+              if (th_valid<DIL>(tp, 2 - k)) dxa[tp][m] = mfma16(wf, dct[tp - (k - 1) * DIL].f[s], dxa[tp][m]);
+          }
+      if (valid) {
+        bf16* dxp = DX + row0 * 64 + 16 * kc;
+#pragma unroll
+        for (int t = 0; t < TH_T; ++t) {
+          float y[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) y[j] = dxa[t][j >> 2][j & 3];
+          th_store(dxp + (int64_t)t * HW * 64, th_pack(y));
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                               // n[t], dgpre[t] of the whole workgroup are resident
+    // ---------------- P2: gate weight gradient ----------------
+#pragma unroll
+    for (int t = 0; t < TH_T; ++t) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int pix0 = ks * 32 + 8 * kc;
+        const frag8 af = th_tr(bufA + t * TH_TILE, pix0, wave * 16, r16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accG[i] = mfma16(af, th_tr(bufB + t * TH_TILE, pix0, i * 16, r16), accG[i]);
+        accGb = mfma16(af, ones, accGb);
+      }
+    }
+    __syncthreads();
+    // ---------------- P3: publish dconv[t], x[t] ----------------
+#pragma unroll
+    for (int t = 0; t < TH_T; ++t) {
+      th_put(bufA + t * TH_TILE, prow, kc, dct[t]);
+      th_put(bufB + t * TH_TILE, prow, kc, x[t]);
+    }
+    __syncthreads();
+    // ---------------- P4: conv weight gradients  dW_k += dconv[tp - (k-1) d]^T x[tp] ----------------
+#pragma unroll
+    for (int tp = 0; tp < TH_T; ++tp) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int pix0 = ks * 32 + 8 * kc;
+        frag8 bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bf[i] = th_tr(bufB + tp * TH_TILE, pix0, i * 16, r16);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          if (!th_valid<DIL>(tp, 2 - k)) continue;
+          const frag8 af = th_tr(bufA + (tp - (k - 1) * DIL) * TH_TILE, pix0, wave * 16, r16);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) accC[k][i] = mfma16(af, bf[i], accC[k][i]);
+          if (k == 1) accCb = mfma16(af, ones, accCb);
+        }
+      }
+    }
+    __syncthreads();                                               // tiles are rewritten by the next workgroup tile
+  }
+  // ---------------- d gamma / d beta: reduce over the 16 pixel lanes, then over waves ----------------
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) { dgam[j] += __shfl_xor(dgam[j], off, 64); dbet[j] += __shfl_xor(dbet[j], off, 64); }
+  }
+  if (px == 0) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { gacc_lds[(wave * 2 + 0) * 64 + 16 * kc + j] = dgam[j]; gacc_lds[(wave * 2 + 1) * 64 + 16 * kc + j] = dbet[j]; }
+  }
+  // ---------------- write this workgroup's slab ----------------
+  float* my = slab + (int64_t)blockIdx.x * TH_SLAB;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) my[(k * 64 + wave * 16 + kc * 4 + r) * 64 + i * 16 + r16] = accC[k][i][r];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) my[(3 * 64 + wave * 16 + kc * 4 + r) * 64 + i * 16 + r16] = accG[i][r];
+  if (r16 == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      my[4 * 64 * 64 + wave * 16 + kc * 4 + r] = accCb[r];
+      my[4 * 64 * 64 + 64 + wave * 16 + kc * 4 + r] = accGb[r];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * 64; i += 256) {
+    const int which = i >> 6, c = i & 63;
+    float s = 0.f;
+    for (int w = 0; w < 4; ++w) s += gacc_lds[(w * 2 + which) * 64 + c];
+    my[4 * 64 * 64 + 128 + i] = s;
+  }
+}
+
+// packs conv taps, gate, gate^T and conv^T taps (lane-quarter A-operand images) in one launch
+__global__ void tcn_hot_pack_kernel(frag8* __restrict__ dst, const float* __restrict__ Wc, const float* __restrict__ Wg) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+  for (int k = 0; k < 3; ++k) pack_weights_lds<bf16, 2>(dst + k * 4 * 2 * 64, Wc + k, 64, 64, 4, 64 * 3, 3, tid, nt);
+  frag8* p = dst + 3 * 4 * 2 * 64;
+  pack_weights_lds<bf16, 2>(p, Wg, 64, 64, 4, 64, 1, tid, nt);
+  p += 4 * 2 * 64;
+  pack_weights_lds<bf16, 2>(p, Wg, 64, 64, 4, 1, 64, tid, nt);
+  p += 4 * 2 * 64;
+  for (int k = 0; k < 3; ++k) pack_weights_lds<bf16, 2>(p + k * 4 * 2 * 64, Wc + k, 64, 64, 4, 3, 64 * 3, tid, nt);   // Weff[o=ci][i=co] = Wc[co][ci][k]
+}
+
+struct ThEpi {
+  float *dWc, *dWg, *dbc, *dbg, *dgam, *dbet;
+  __device__ void operator()(int64_t i, float s) const {
+    if (i < 3 * 4096) {
+      const int k = (int)(i / 4096), co = (int)((i % 4096) / 64), ci = (int)(i % 64);
+      dWc[(co * 64 + ci) * 3 + k] = s;
+    } else if (i < 4 * 4096) {
+      dWg[i - 3 * 4096] = s;
+    } else {
+      const int j = (int)(i - 4 * 4096);
+      if (j < 64) dbc[j] = s; else if (j < 128) dbg[j - 64] = s; else if (j < 192) dgam[j - 128] = s; else dbet[j - 192] = s;
+    }
+  }
+};
+
+static unsigned th_bwd_grid(int64_t npix) {
+  int64_t g = (npix + 63) / 64;
+  if (g > 256) g = 256;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+static unsigned th_fwd_grid(int64_t npix) {
+  int64_t g = ((npix + 15) / 16 + 3) / 4;
+  if (g > 512) g = 512;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+static constexpr size_t TH_PACK_BYTES = (size_t)64 * 64 * sizeof(frag8);
+static constexpr size_t TH_FWD_LDS = (size_t)32 * 64 * sizeof(frag8) + 4 * 64 * sizeof(float);
+static constexpr size_t TH_BWD_LDS = TH_PACK_BYTES + (size_t)(4 * 64 + 4 * 2 * 64) * sizeof(float) + (size_t)2 * TH_T * TH_TILE * sizeof(bf16);
+
+template <int DIL>
+static int th_launch_fwd(const void* x, const frag8* pk, const float* bc, const float* gw, const float* gb, const float* bg, void* y,
+                         int64_t npix, int HW, float eps, hipStream_t st) {
+  auto kern = tcn_hot_fwd_kernel<DIL>;
+  FRL_LAUNCH(kern, dim3(th_fwd_grid(npix)), dim3(256), TH_FWD_LDS, st, (const bf16*)x, pk, bc, gw, gb, bg, (bf16*)y, npix, HW, eps);
+  return 0;
+}
+template <int DIL>
+static int th_launch_bwd(const void* x, const void* dy, const frag8* pk, const float* bc, const float* gw, const float* gb, const float* bg,
+                         void* dx, float* slab, unsigned grid, int64_t npix, int HW, float eps, hipStream_t st) {
+  auto kern = tcn_hot_bwd_kernel<DIL>;
+  FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TH_BWD_LDS));
+  FRL_LAUNCH(kern, dim3(grid), dim3(256), TH_BWD_LDS, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx, slab, npix, HW, eps);
+  return 0;
+}
+
+extern "C" {
+
+// 1 when the specialised kernels apply: bf16, 64 -> 64 channels, T = 5, 8 groups, identity residual, dilation 1 / 2 / 4
+int frl_tcn_hot_supported(int T, int Cin, int Cout, int G, int dilation, int has_proj, int dtype) {
+  return dtype == FRL_BF16 && Cin == 64 && Cout == 64 && T == TH_T && G == 8 && !has_proj && (dilation == 1 || dilation == 2 || dilation == 4);
+}
+
+size_t frl_tcn_hot_fwd_workspace_bytes(void) { return TH_PACK_BYTES; }
+size_t frl_tcn_hot_bwd_workspace_bytes(int64_t npix) { return (size_t)th_bwd_grid(npix) * TH_SLAB * sizeof(float) + 256 + TH_PACK_BYTES; }
+
+// x, y [B][5][HW][64] bf16; parameters float32 in the reference layouts (conv_w [64][64][3], gate_w [64][64])
+int frl_tcn_hot_fwd(const void* x, const float* conv_w, const float* conv_b, const float* gn_w, const float* gn_b, const float* gate_w,
+                    const float* gate_b, void* y, int64_t npix, int HW, int dilation, float eps, void* ws, size_t ws_bytes,
+                    hipStream_t stream) {
+  if (npix <= 0 || HW <= 0) return frl_fail(-2, "tcn_hot_fwd: empty input");
+  if (ws == nullptr || ws_bytes < TH_PACK_BYTES) return frl_fail(-4, "tcn_hot_fwd: workspace too small");
+  frag8* pk = (frag8*)ws;
+  FRL_LAUNCH(tcn_hot_pack_kernel, dim3(32), dim3(256), 0, stream, pk, conv_w, gate_w);
+  int rc = -2;
+  if (dilation == 1) rc = th_launch_fwd<1>(x, pk, conv_b, gn_w, gn_b, gate_b, y, npix, HW, eps, stream);
+  else if (dilation == 2) rc = th_launch_fwd<2>(x, pk, conv_b, gn_w, gn_b, gate_b, y, npix, HW, eps, stream);
+  else if (dilation == 4) rc = th_launch_fwd<4>(x, pk, conv_b, gn_w, gn_b, gate_b, y, npix, HW, eps, stream);
+  else return frl_fail(-2, "tcn_hot_fwd: dilation must be 1, 2 or 4");
+  if (rc) return rc;
+  return frl_check_launch("tcn_hot_fwd");
+}
+
+// one launch: dx [B][5][HW][64] bf16 and all parameter gradients (float32, reference layouts)
+int frl_tcn_hot_bwd(const void* x, const void* dy, const float* conv_w, const float* conv_b, const float* gn_w, const float* gn_b,
+                    const float* gate_w, const float* gate_b, void* dx, float* d_conv_w, float* d_conv_b, float* d_gn_w, float* d_gn_b,
+                    float* d_gate_w, float* d_gate_b, int64_t npix, int HW, int dilation, float eps, void* ws, size_t ws_bytes,
+                    hipStream_t stream) {
+  if (npix <= 0 || HW <= 0) return frl_fail(-2, "tcn_hot_bwd: empty input");
+  if (ws == nullptr || ws_bytes < frl_tcn_hot_bwd_workspace_bytes(npix)) return frl_fail(-4, "tcn_hot_bwd: workspace too small");
+  const unsigned grid = th_bwd_grid(npix);
+  float* slab = (float*)ws;
+  frag8* pk = reinterpret_cast<frag8*>(reinterpret_cast<char*>(ws) + (((size_t)grid * TH_SLAB * sizeof(float) + 255) / 256) * 256);
+  FRL_LAUNCH(tcn_hot_pack_kernel, dim3(32), dim3(256), 0, stream, pk, conv_w, gate_w);
+  int rc = -2;
+  if (dilation == 1) rc = th_launch_bwd<1>(x, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
+  else if (dilation == 2) rc = th_launch_bwd<2>(x, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
+  else if (dilation == 4) rc = th_launch_bwd<4>(x, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
+  else return frl_fail(-2, "tcn_hot_bwd: dilation must be 1, 2 or 4");
+  if (rc) return rc;
+  launch_slab_reduce<float, ThEpi>((const float*)slab, (int)grid, (int64_t)TH_SLAB, ThEpi{d_conv_w, d_gate_w, d_conv_b, d_gate_b, d_gn_w, d_gn_b},
+                                   stream);
+  return frl_check_launch("tcn_hot_bwd");
+}
+
+}  // extern "C"

@@ -405,12 +405,18 @@ def edge_smooth_bwd(d_smoothed, x, a_soft, b_soft, rank: int, coarse_dilation: i
 # ----------------------------------------------------------------------------------------------
 @_timed("tcn_block_fwd")
 def tcn_block_fwd(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, dilation: int, groups: int,
-                  eps: float = 1e-5):
+                  eps: float = 1e-5, allow_hot: bool = True):
     b, t, cin = x.shape[0], x.shape[1], x.shape[-1]
     cout = conv_w.shape[0]
     hw = x.numel() // (b * t * cin)
     y = torch.empty(x.shape[:-1] + (cout,), dtype=x.dtype, device=x.device)
     lib = _lib.load()
+    if allow_hot and lib.frl_tcn_hot_supported(t, cin, cout, groups, dilation, int(proj_w is not None), _dt(x)):
+        ws = workspace(lib.frl_tcn_hot_fwd_workspace_bytes(), x.device)
+        check(lib.frl_tcn_hot_fwd(_p(x), _p(_f32(conv_w, "conv_w")), _p(conv_b), _p(gn_w), _p(gn_b),
+                                  _p(_f32(gate_w.reshape(cout, cout), "gate_w")), _p(gate_b), _p(y), b * hw, hw, dilation, float(eps),
+                                  _p(ws), ws.numel(), _stream()), "frl_tcn_hot_fwd")
+        return y
     ws = workspace(lib.frl_conv_workspace_bytes(max(cin, cout), cout, 6), x.device)
     check(lib.frl_tcn_block_fwd(_p(x), _p(_f32(conv_w, "conv_w")), _p(conv_b), _p(gn_w), _p(gn_b),
                                 _p(_f32(gate_w.reshape(cout, cout), "gate_w")), _p(gate_b), _p(proj_w), _p(proj_b),
@@ -421,7 +427,7 @@ def tcn_block_fwd(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b,
 
 @_timed("tcn_block_bwd")
 def tcn_block_bwd(x, dy, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, dilation: int, groups: int,
-                  eps: float = 1e-5, allow_fused: bool = True):
+                  eps: float = 1e-5, allow_fused: bool = True, allow_hot: bool = True):
     """Returns dict(dx, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b[, proj_w, proj_b]) gradients."""
     b, t, cin = x.shape[0], x.shape[1], x.shape[-1]
     cout = conv_w.shape[0]
@@ -429,6 +435,17 @@ def tcn_block_bwd(x, dy, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, pro
     npix = b * hw
     lib = _lib.load()
     dev = x.device
+    if allow_fused and allow_hot and lib.frl_tcn_hot_supported(t, cin, cout, groups, dilation, int(proj_w is not None), _dt(x)):
+        dx = torch.empty_like(x)
+        g = {k: torch.empty_like(v, dtype=torch.float32) for k, v in
+             dict(conv_w=conv_w, conv_b=conv_b, gn_w=gn_w, gn_b=gn_b, gate_w=gate_w, gate_b=gate_b).items()}
+        ws = workspace(lib.frl_tcn_hot_bwd_workspace_bytes(npix), dev)
+        with span("tcn_block_bwd.main"):
+            check(lib.frl_tcn_hot_bwd(_p(x), _p(dy), _p(conv_w), _p(conv_b), _p(gn_w), _p(gn_b), _p(gate_w.reshape(cout, cout)), _p(gate_b),
+                                      _p(dx), _p(g["conv_w"]), _p(g["conv_b"]), _p(g["gn_w"]), _p(g["gn_b"]), _p(g["gate_w"]),
+                                      _p(g["gate_b"]), npix, hw, dilation, float(eps), _p(ws), ws.numel(), _stream()), "frl_tcn_hot_bwd")
+        g["dx"] = dx
+        return g
     if allow_fused and lib.frl_tcn_block_bwd_fused_supported(t, cin, cout, groups, int(proj_w is not None), _dt(x)):
         dx = torch.empty_like(x)
         g = {k: torch.empty_like(v, dtype=torch.float32) for k, v in
