@@ -1,0 +1,8 @@
+#!/bin/bash
+# builds the diagnostic harnesses (binaries are git-ignored; they travel to the GPU box with gpurun)
+set -e
+cd "$(dirname "$0")"
+CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I ../../vq-vae_amd/csrc -I ../../include"
+$CC -o tcn_bwd_v2.bin tcn_bwd_stamps.hip
+$CC -DTH_STAMPS -o tcn_bwd_v2_stamps.bin tcn_bwd_stamps.hip
+$CC -DTH_BWD_V1 -o tcn_bwd_v1.bin tcn_bwd_stamps.hip

@@ -21,6 +21,14 @@
 #include "frl_reduce.hpp"
 
 #define TH_T 5
+// Diagnostic build only (tools/diag/tcn_bwd_stamps.hip defines TH_STAMPS): s_memtime stamps at the phase boundaries of the
+// backward kernel, written to a buffer nothing else reads.  The product library never defines it.
+#ifdef TH_STAMPS
+__device__ unsigned long long* th_dbg;
+#define TH_STAMP(i) do { if (lane == 0 && wt_iter < 16) th_dbg[(((size_t)blockIdx.x * 4 + wave) * 16 + wt_iter) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TH_STAMP(i) do { } while (0)
+#endif
 #define TH_PITCH 72       // bf16 elements per pixel row in LDS tiles (64 + 8: conflict-free 16-byte writes and tr16 reads)
 
 typedef bf16x8 frag8;
@@ -233,7 +241,9 @@ __global__ __launch_bounds__(256) void tcn_hot_bwd_kernel(const bf16* __restrict
                                 : frag8{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
 
   const int64_t nwt = (npix + 63) >> 6;
-  for (int64_t wt = blockIdx.x; wt < nwt; wt += gridDim.x) {
+  int wt_iter = 0;
+  for (int64_t wt = blockIdx.x; wt < nwt; wt += gridDim.x, ++wt_iter) {
+    TH_STAMP(0);
     int64_t pidx = wt * 64 + prow;
     const bool valid = pidx < npix;
     if (!valid) pidx = npix - 1;
@@ -256,9 +266,11 @@ __global__ __launch_bounds__(256) void tcn_hot_bwd_kernel(const bf16* __restrict
     th_conv<DIL>(acc, x, wl_conv, lane);
     float mean[2], rstd[2];
     th_stats(acc, eps, mean, rstd);
+    TH_STAMP(1);
     const float nm[2] = {-mean[0] * rstd[0], -mean[1] * rstd[1]};
     float S1[2] = {0.f, 0.f}, S2[2] = {0.f, 0.f};
-    Tile2 dr[TH_T], dxh[TH_T];
+    Tile2 dxh[TH_T];
+    bf16* dxp = DX + row0 * 64 + 16 * kc;                          // dres[t] is parked in dx (L2) until the conv^T pass
 #pragma unroll
     for (int t = 0; t < TH_T; ++t) {
       __builtin_amdgcn_sched_barrier(0);
@@ -296,7 +308,7 @@ __global__ __launch_bounds__(256) void tcn_hot_bwd_kernel(const bf16* __restrict
       }
       const Tile2 gt = th_pack(dgp);
       th_put(bufA + t * TH_TILE, prow, kc, gt);
-      dr[t] = th_pack(drv);
+      if (valid) th_store(dxp + (int64_t)t * HW * 64, th_pack(drv));   // (a clamped lane must not touch its alias)
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -314,6 +326,7 @@ __global__ __launch_bounds__(256) void tcn_hot_bwd_kernel(const bf16* __restrict
       dxh[t] = th_pack(d);
     }
     __builtin_amdgcn_sched_barrier(0);
+    TH_STAMP(2);
     Tile2 dct[TH_T];
     {
       const float m1[2] = {S1[0] * (1.f / 40.f), S1[1] * (1.f / 40.f)};
@@ -332,10 +345,12 @@ __global__ __launch_bounds__(256) void tcn_hot_bwd_kernel(const bf16* __restrict
     {
       f32x4 dxa[TH_T][4];
 #pragma unroll
-      for (int t = 0; t < TH_T; ++t)
+      for (int t = 0; t < TH_T; ++t) {
+        const Tile2 drt = th_load(dxp + (int64_t)t * HW * 64);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-          dxa[t][m] = f32x4{th_elem(dr[t], 4 * m), th_elem(dr[t], 4 * m + 1), th_elem(dr[t], 4 * m + 2), th_elem(dr[t], 4 * m + 3)};
+          dxa[t][m] = f32x4{th_elem(drt, 4 * m), th_elem(drt, 4 * m + 1), th_elem(drt, 4 * m + 2), th_elem(drt, 4 * m + 3)};
+      }
 #pragma unroll
       for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -348,7 +363,6 @@ __global__ __launch_bounds__(256) void tcn_hot_bwd_kernel(const bf16* __restrict
               if (th_valid<DIL>(tp, 2 - k)) dxa[tp][m] = mfma16(wf, dct[tp - (k - 1) * DIL].f[s], dxa[tp][m]);
           }
       if (valid) {
-        bf16* dxp = DX + row0 * 64 + 16 * kc;
 #pragma unroll
         for (int t = 0; t < TH_T; ++t) {
           float y[16];
@@ -359,7 +373,9 @@ __global__ __launch_bounds__(256) void tcn_hot_bwd_kernel(const bf16* __restrict
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    TH_STAMP(3);
     __syncthreads();                                               // n[t], dgpre[t] of the whole workgroup are resident
+    TH_STAMP(4);
     // ---------------- P2: gate weight gradient ----------------
 #pragma unroll
     for (int t = 0; t < TH_T; ++t) {
@@ -373,6 +389,7 @@ __global__ __launch_bounds__(256) void tcn_hot_bwd_kernel(const bf16* __restrict
         accGb = mfma16(af, ones, accGb);
       }
     }
+    TH_STAMP(5);
     __syncthreads();
     // ---------------- P3: publish dconv[t], x[t] ----------------
 #pragma unroll
@@ -381,6 +398,7 @@ __global__ __launch_bounds__(256) void tcn_hot_bwd_kernel(const bf16* __restrict
       th_put(bufB + t * TH_TILE, prow, kc, x[t]);
     }
     __syncthreads();
+    TH_STAMP(6);
     // ---------------- P4: conv weight gradients  dW_k += dconv[tp - (k-1) d]^T x[tp] ----------------
 #pragma unroll
     for (int tp = 0; tp < TH_T; ++tp) {
@@ -401,6 +419,7 @@ __global__ __launch_bounds__(256) void tcn_hot_bwd_kernel(const bf16* __restrict
         }
       }
     }
+    TH_STAMP(7);
     __syncthreads();                                               // tiles are rewritten by the next workgroup tile
   }
   // ---------------- d gamma / d beta: reduce over the 16 pixel lanes, then over waves ----------------
@@ -434,6 +453,369 @@ __global__ __launch_bounds__(256) void tcn_hot_bwd_kernel(const bf16* __restrict
   }
   __syncthreads();
   for (int i = tid; i < 2 * 64; i += 256) {
+    const int which = i >> 6, c = i & 63;
+    float s = 0.f;
+    for (int w = 0; w < 4; ++w) s += gacc_lds[(w * 2 + which) * 64 + c];
+    my[4 * 64 * 64 + 128 + i] = s;
+  }
+}
+
+// =============================================================================================================
+// backward, 8 waves per workgroup (two per SIMD): wave (q, h) owns the 16 pixels of quarter q and the channel half h of every
+// lane quarter (fragment h of the lane-quarter image = one 8-channel GroupNorm group per lane), i.e. half the per-lane state of
+// the 4-wave kernel above, so the compiler keeps everything in registers and two waves per SIMD hide each other's LDS / MFMA
+// latencies.  The GEMMs that contract over all 64 channels (gate, gate^T, conv^T) take the partner wave's half from the very
+// LDS tiles that are published for the weight-gradient GEMMs anyway:
+//   S1  conv -> GroupNorm statistics -> n[t]                                  publish n[t]        | barrier A
+//   S2  gate GEMM, sigmoid, dgpre[t], dres[t] (parked in dx), relu path of dn  publish dgpre[t]    | barrier B
+//   S3  gate^T GEMM -> dn -> d gamma, d beta, GroupNorm backward -> dconv[t];  P2 gate weight gradient (rows 16q.., column half h)
+//                                                                                                  | barrier C
+//   P3  publish dconv[t], x[t]                                                                     | barrier D
+//   dx = conv^T(dconv) + dres (stored);  P4 conv weight gradients                                  | barrier E
+// =============================================================================================================
+__device__ __forceinline__ frag8 th_pack8(const float (&v)[8]) {
+  frag8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+  return o;
+}
+__device__ __forceinline__ Tile2 th_get(const bf16* tile, int prow, int kc) {
+  const frag8* p = reinterpret_cast<const frag8*>(tile + prow * TH_PITCH + 16 * kc);
+  Tile2 t;
+  t.f[0] = p[0];
+  t.f[1] = p[1];
+  return t;
+}
+
+template <int DIL>
+__global__ __launch_bounds__(512, 2) void tcn_hot_bwd2_kernel(const bf16* __restrict__ X, const bf16* __restrict__ DY,
+                                                              const frag8* __restrict__ Wpk, const float* __restrict__ bc,
+                                                              const float* __restrict__ gn_w, const float* __restrict__ gn_b,
+                                                              const float* __restrict__ bg, bf16* DX, float* __restrict__ slab,
+                                                              int64_t npix, int HW, float eps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  frag8* wl_conv = reinterpret_cast<frag8*>(smem);               // [3][4][2][64]
+  frag8* wl_gate = wl_conv + 24 * 64;                            // [4][2][64]
+  frag8* wl_gateT = wl_gate + 8 * 64;                            // [4][2][64]
+  frag8* wl_convT = wl_gateT + 8 * 64;                           // [3][4][2][64]
+  float* tab = reinterpret_cast<float*>(wl_convT + 24 * 64);     // conv bias | gamma | beta | -log2e * gate bias
+  float* gacc_lds = tab + 4 * 64;                                // [8 waves][2][32]
+  bf16* bufA = reinterpret_cast<bf16*>(gacc_lds + 4 * 2 * 64);   // [T][64 px][PITCH]  dgpre[t], later dconv[t]
+  bf16* bufB = bufA + TH_T * TH_TILE;                            // [T][64 px][PITCH]  n[t],     later x[t]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = wave & 3, h = wave >> 2;
+  const int px = lane & 15, kc = lane >> 4, r16 = px;
+  const int prow = q * 16 + px;
+  const int co = 16 * kc + 8 * h;                                // first of this lane's 8 channels
+#ifdef TH_STAMPS
+  __shared__ unsigned long long th_ts[8][12];
+  if (tid < 96) (&th_ts[0][0])[tid] = 0ull;
+  unsigned long long t_prev = 0;
+#define TH_ST2(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); if (lane == 0) th_ts[wave][i] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define TH_ST2(i) do { } while (0)
+#endif
+
+  copy_frags_lds<bf16>(wl_conv, Wpk, 64 * 64, tid, 512);
+  if (tid < 64) {
+    tab[tid] = bc[tid];
+    tab[64 + tid] = gn_w[tid];
+    tab[128 + tid] = gn_b[tid];
+    tab[192 + tid] = -1.44269504088896f * bg[tid];
+  }
+  __syncthreads();
+  float gw[8], gb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { gw[e] = tab[64 + co + e]; gb[e] = tab[128 + co + e]; }
+  const float* tnbg = tab + 192 + co;
+  const f32x4* tcb = reinterpret_cast<const f32x4*>(tab + co);
+  const frag8* wc_own = wl_conv + (2 * h) * 2 * 64 + lane;       // + ((k*4 + mm)*2 + s)*64
+  const frag8* wg_own = wl_gate + (2 * h) * 2 * 64 + lane;       // + (mm*2 + s)*64
+  const frag8* wgT_own = wl_gateT + (2 * h) * 2 * 64 + lane;
+  const frag8* wcT_own = wl_convT + (2 * h) * 2 * 64 + lane;
+
+  f32x4 accC[3][2], accG[2], accCb = {0.f, 0.f, 0.f, 0.f}, accGb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) accC[k][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) accG[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dgam[8], dbet[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { dgam[e] = 0.f; dbet[e] = 0.f; }
+  const frag8 ones = (r16 == 0) ? frag8{(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f}
+                                : frag8{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+
+  const int nwt = (int)((npix + 63) >> 6);
+  const int64_t tstride = (int64_t)HW * 64;
+  // this lane's pixel of workgroup tile `wt`: row offset (elements) of its time step 0, or of the last pixel when out of range
+  auto pix_off = [&](int wt, bool& ok) -> int64_t {
+    unsigned pidx = (unsigned)wt * 64u + (unsigned)prow;
+    ok = pidx < (unsigned)npix;
+    if (!ok) pidx = (unsigned)npix - 1u;
+    const unsigned b = pidx / (unsigned)HW, hw = pidx - b * (unsigned)HW;
+    return ((int64_t)b * TH_T * HW + hw) * 64;
+  };
+#ifdef TH_STAMPS
+  t_prev = __builtin_amdgcn_s_memtime();
+#endif
+  for (int wt = blockIdx.x; wt < nwt; wt += gridDim.x) {
+    bool cur_valid;
+    const int64_t off = pix_off(wt, cur_valid);
+    bf16* dxp = DX + off + co;
+    Tile2 x[TH_T];
+    frag8 dyo[TH_T];
+#pragma unroll
+    for (int t = 0; t < TH_T; ++t) x[t] = th_load(X + off + 16 * kc + t * tstride);
+#pragma unroll
+    for (int t = 0; t < TH_T; ++t) dyo[t] = *reinterpret_cast<const frag8*>(DY + off + co + t * tstride);
+    frag8 xo[TH_T];
+    f32x4 xh[TH_T][2];
+    float mean, rstd;
+    {
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm) {
+        const f32x4 cb = tcb[mm];
+#pragma unroll
+        for (int t = 0; t < TH_T; ++t) xh[t][mm] = cb;
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const frag8 wf = wc_own[((k * 4 + mm) * 2 + s) * 64];
+#pragma unroll
+            for (int t = 0; t < TH_T; ++t)
+              if (th_valid<DIL>(t, k)) xh[t][mm] = mfma16(wf, x[t + (k - 1) * DIL].f[s], xh[t][mm]);
+          }
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t) xo[t] = h ? x[t].f[1] : x[t].f[0];
+    }
+    if (!cur_valid) {                                              // clamped duplicate pixel: contributes nothing
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t) dyo[t] = frag8{};
+    }
+    {                                                              // exact two-pass statistics of this lane's group (8 ch x 5 t)
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += xh[t][e >> 2][e & 3];
+      mean = s * (1.f / 40.f);
+      float qq = 0.f;
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = xh[t][e >> 2][e & 3] - mean; qq = fmaf(d, d, qq); }
+      rstd = 1.f / sqrtf(qq * (1.f / 40.f) + eps);
+    }
+    // ---------------- S1: xhat, n[t] -> LDS ----------------
+    {
+      const float nm = -mean * rstd;
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t) {
+        float n[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = fmaf(xh[t][e >> 2][e & 3], rstd, nm);
+          xh[t][e >> 2][e & 3] = v;
+          n[e] = fmaf(v, gw[e], gb[e]);
+        }
+        *reinterpret_cast<frag8*>(bufB + t * TH_TILE + prow * TH_PITCH + co) = th_pack8(n);
+      }
+    }
+    TH_ST2(0);
+    __syncthreads();                                               // A: n[t] complete (all channels of every pixel)
+    TH_ST2(1);
+    // ---------------- S2: gate, dgpre, dres, relu path of dn ----------------
+    frag8 dn0[TH_T];
+#pragma unroll
+    for (int t = 0; t < TH_T; ++t) {
+      const Tile2 nt = th_get(bufB + t * TH_TILE, prow, kc);
+      f32x4 gacc[2];
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm) {
+        gacc[mm] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) gacc[mm] = mfma16(wg_own[(mm * 2 + s) * 64], nt.f[s], gacc[mm]);
+      }
+      float dgp[8], drv[8], dnr[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float n = fmaf(xh[t][e >> 2][e & 3], gw[e], gb[e]);
+        const float dyv = (float)dyo[t][e];
+        const float g = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(gacc[e >> 2][e & 3], -1.44269504088896f, tnbg[e])));
+        const float o = fmaxf(n, 0.f);
+        const float res = (float)xo[t][e];
+        const float dyg = dyv * g;
+        drv[e] = dyv - dyg;                                        // dy (1 - g)
+        dgp[e] = (o - res) * (dyg - dyg * g);                      // dy (o - res) g (1 - g)
+        dnr[e] = n > 0.f ? dyg : 0.f;
+      }
+      *reinterpret_cast<frag8*>(bufA + t * TH_TILE + prow * TH_PITCH + co) = th_pack8(dgp);
+      if (cur_valid) *reinterpret_cast<frag8*>(dxp + t * tstride) = th_pack8(drv);   // (a clamped lane must not touch its alias)
+      dn0[t] = th_pack8(dnr);
+    }
+    TH_ST2(2);
+    __syncthreads();                                               // B: dgpre[t] complete
+    TH_ST2(3);
+    // ---------------- S3: gate^T, dn, GroupNorm backward ----------------
+    frag8 dcf[TH_T];
+    {
+      float S1 = 0.f, S2 = 0.f;
+      frag8 dxh[TH_T];
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t) {
+        const Tile2 gt = th_get(bufA + t * TH_TILE, prow, kc);
+        float dd[8];
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+          f32x4 bacc = {(float)dn0[t][4 * mm], (float)dn0[t][4 * mm + 1], (float)dn0[t][4 * mm + 2], (float)dn0[t][4 * mm + 3]};
+#pragma unroll
+          for (int s = 0; s < 2; ++s) bacc = mfma16(wgT_own[(mm * 2 + s) * 64], gt.f[s], bacc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e = 4 * mm + r;
+            const float dnv = bacc[r], xv = xh[t][mm][r];
+            dgam[e] = fmaf(dnv, xv, dgam[e]);
+            dbet[e] += dnv;
+            const float d = dnv * gw[e];
+            dd[e] = d;
+            S1 += d;
+            S2 = fmaf(d, xv, S2);
+          }
+        }
+        dxh[t] = th_pack8(dd);
+      }
+      const float m1 = S1 * (1.f / 40.f), m2 = S2 * (1.f / 40.f);
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t) {
+        float dc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dc[e] = rstd * ((float)dxh[t][e] - m1 - xh[t][e >> 2][e & 3] * m2);
+        dcf[t] = th_pack8(dc);
+      }
+    }
+    TH_ST2(4);
+    // ---------------- P2: gate weight gradient (rows 16q.., columns 32h..) ----------------
+#pragma unroll
+    for (int t = 0; t < TH_T; ++t) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int pix0 = ks * 32 + 8 * kc;
+        const frag8 af = th_tr(bufA + t * TH_TILE, pix0, q * 16, r16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) accG[i] = mfma16(af, th_tr(bufB + t * TH_TILE, pix0, (2 * h + i) * 16, r16), accG[i]);
+        accGb = mfma16(af, ones, accGb);
+      }
+    }
+    TH_ST2(5);
+    __syncthreads();                                               // C: everyone is done with n[t], dgpre[t]
+    TH_ST2(6);
+    // ---------------- P3: publish dconv[t], x[t] ----------------
+#pragma unroll
+    for (int t = 0; t < TH_T; ++t) {
+      *reinterpret_cast<frag8*>(bufA + t * TH_TILE + prow * TH_PITCH + co) = dcf[t];
+      *reinterpret_cast<frag8*>(bufB + t * TH_TILE + prow * TH_PITCH + co) = xo[t];
+    }
+    __syncthreads();                                               // D
+    TH_ST2(7);
+    // ---------------- dx[t'] = sum_k W_k^T dconv[t' - (k-1) d] + dres[t'] (this wave's 8 channels per lane) ----------------
+    {
+      f32x4 dxa[TH_T][2];
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t) {
+        const frag8 drt = *reinterpret_cast<const frag8*>(dxp + t * tstride);
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+          dxa[t][mm] = f32x4{(float)drt[4 * mm], (float)drt[4 * mm + 1], (float)drt[4 * mm + 2], (float)drt[4 * mm + 3]};
+      }
+      Tile2 dct[TH_T];
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t) dct[t] = th_get(bufA + t * TH_TILE, prow, kc);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const frag8 wf = wcT_own[((k * 4 + mm) * 2 + s) * 64];
+#pragma unroll
+            for (int tp = 0; tp < TH_T; ++tp)
+              if (th_valid<DIL>(tp, 2 - k)) dxa[tp][mm] = mfma16(wf, dct[tp - (k - 1) * DIL].f[s], dxa[tp][mm]);
+          }
+      if (cur_valid) {
+#pragma unroll
+        for (int t = 0; t < TH_T; ++t) {
+          float y[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = dxa[t][e >> 2][e & 3];
+          *reinterpret_cast<frag8*>(dxp + t * tstride) = th_pack8(y);
+        }
+      }
+    }
+    TH_ST2(8);
+    // ---------------- P4: conv weight gradients  dW_k += dconv[tp - (k-1) d]^T x[tp] ----------------
+#pragma unroll
+    for (int tp = 0; tp < TH_T; ++tp) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int pix0 = ks * 32 + 8 * kc;
+        frag8 bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) bf[i] = th_tr(bufB + tp * TH_TILE, pix0, (2 * h + i) * 16, r16);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          if (!th_valid<DIL>(tp, 2 - k)) continue;
+          const frag8 af = th_tr(bufA + (tp - (k - 1) * DIL) * TH_TILE, pix0, q * 16, r16);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) accC[k][i] = mfma16(af, bf[i], accC[k][i]);
+          if (k == 1) accCb = mfma16(af, ones, accCb);
+        }
+      }
+    }
+    TH_ST2(9);
+    __syncthreads();                                               // E: tiles are rewritten by the next workgroup tile
+    TH_ST2(10);
+  }
+#ifdef TH_STAMPS
+  __syncthreads();
+  if (tid < 96) th_dbg[(size_t)blockIdx.x * 96 + tid] = (&th_ts[0][0])[tid];
+#endif
+  // ---------------- d gamma / d beta: reduce over the 16 pixel lanes, then over the 4 pixel quarters ----------------
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) { dgam[e] += __shfl_xor(dgam[e], off, 64); dbet[e] += __shfl_xor(dbet[e], off, 64); }
+  }
+  if (px == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gacc_lds[(q * 2 + 0) * 64 + co + e] = dgam[e]; gacc_lds[(q * 2 + 1) * 64 + co + e] = dbet[e]; }
+  }
+  // ---------------- write this workgroup's slab (rows 16q.., columns 32h..) ----------------
+  float* my = slab + (int64_t)blockIdx.x * TH_SLAB;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) my[(k * 64 + q * 16 + kc * 4 + r) * 64 + (2 * h + i) * 16 + r16] = accC[k][i][r];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) my[(3 * 64 + q * 16 + kc * 4 + r) * 64 + (2 * h + i) * 16 + r16] = accG[i][r];
+  if (r16 == 0 && h == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      my[4 * 64 * 64 + q * 16 + kc * 4 + r] = accCb[r];
+      my[4 * 64 * 64 + 64 + q * 16 + kc * 4 + r] = accGb[r];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * 64; i += 512) {
     const int which = i >> 6, c = i & 63;
     float s = 0.f;
     for (int w = 0; w < 4; ++w) s += gacc_lds[(w * 2 + which) * 64 + c];
@@ -494,9 +876,15 @@ static int th_launch_fwd(const void* x, const frag8* pk, const float* bc, const 
 template <int DIL>
 static int th_launch_bwd(const void* x, const void* dy, const frag8* pk, const float* bc, const float* gw, const float* gb, const float* bg,
                          void* dx, float* slab, unsigned grid, int64_t npix, int HW, float eps, hipStream_t st) {
+#ifdef TH_BWD_V1
   auto kern = tcn_hot_bwd_kernel<DIL>;
+  const unsigned nthr = 256;
+#else
+  auto kern = tcn_hot_bwd2_kernel<DIL>;
+  const unsigned nthr = 512;
+#endif
   FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TH_BWD_LDS));
-  FRL_LAUNCH(kern, dim3(grid), dim3(256), TH_BWD_LDS, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx, slab, npix, HW, eps);
+  FRL_LAUNCH(kern, dim3(grid), dim3(nthr), TH_BWD_LDS, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx, slab, npix, HW, eps);
   return 0;
 }
 
@@ -533,6 +921,7 @@ int frl_tcn_hot_bwd(const void* x, const void* dy, const float* conv_w, const fl
                     float* d_gate_w, float* d_gate_b, int64_t npix, int HW, int dilation, float eps, void* ws, size_t ws_bytes,
                     hipStream_t stream) {
   if (npix <= 0 || HW <= 0) return frl_fail(-2, "tcn_hot_bwd: empty input");
+  if (npix >= (int64_t)1 << 31) return frl_fail(-2, "tcn_hot_bwd: more than 2^31 pixels per launch");
   if (ws == nullptr || ws_bytes < frl_tcn_hot_bwd_workspace_bytes(npix)) return frl_fail(-4, "tcn_hot_bwd: workspace too small");
   const unsigned grid = th_bwd_grid(npix);
   float* slab = (float*)ws;
