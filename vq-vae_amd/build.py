@@ -52,7 +52,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
                     sys.stderr.write(log)
                     raise RuntimeError(f"hipcc failed for {s}")
     objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in srcs]
-    if jobs or not os.path.exists(OUT):
+    if jobs or not os.path.exists(OUT) or any(os.path.getmtime(o) > os.path.getmtime(OUT) for o in objs):
         r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs,
                            capture_output=True, text=True)
         if r.returncode != 0:

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, kc = lane >> 4;
   const int tiles_x = (W + C3_TW - 1) / C3_TW, tiles_y = (H + C3F_TH - 1) / C3F_TH;
-  const int bid = blockIdx.x;
+  const int bid = (int)xcd_remap(blockIdx.x, gridDim.x);     // the tiles of one image share an XCD (halo rows hit its L2)
   const int b = bid / (tiles_x * tiles_y), tyx = bid % (tiles_x * tiles_y);
   const int y0 = (tyx / tiles_x) * C3F_TH, x0 = (tyx % tiles_x) * C3_TW;
   const int MB = (Cout + 15) >> 4, qo = 4 * MB;

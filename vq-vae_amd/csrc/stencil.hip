@@ -34,7 +34,7 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void sobel_fwd_kernel(const T* __restrict__ X, T* __restrict__ G, int B, int H, int W, int C) {
   const int vpr = C / V;
   const int64_t total = (int64_t)B * H * W * vpr;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c0 = (int)(i % vpr) * V;
     const int64_t p = i / vpr;
     const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
@@ -62,7 +62,7 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void sobel_bwd_kernel(const T* __restrict__ DG, T* __restrict__ DX, int B, int H, int W, int C) {
   const int vpr = C / V;
   const int64_t total = (int64_t)B * H * W * vpr;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c0 = (int)(i % vpr) * V;
     const int64_t p = i / vpr;
     const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void smooth_fwd_kernel(const T* __restrict__ X
   const int vpr = C / V;
   const int ppw = 256 / tpp;
   const int64_t npix = (int64_t)B * H * W;
-  for (int64_t p = (int64_t)blockIdx.x * ppw + threadIdx.x / tpp; p < npix; p += (int64_t)gridDim.x * ppw) {
+  // XCD-aware block order: the rows of one image (and their +-1 / +-3 row neighbours) stay in one XCD's L2
+  for (int64_t p = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * ppw + threadIdx.x / tpp; p < npix; p += (int64_t)gridDim.x * ppw) {
     const int cvi = threadIdx.x % tpp;
     if (cvi >= vpr) continue;
     const int c0 = cvi * V;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(const T* __restrict__ D
   const int64_t npix = (int64_t)B * H * W;
   const int64_t nloop = (npix + ppw - 1) / ppw;
   const float third = 1.f / 3.f;
-  for (int64_t it = blockIdx.x; it < nloop; it += gridDim.x) {
+  for (int64_t it = xcd_remap(blockIdx.x, gridDim.x); it < nloop; it += gridDim.x) {
     const int64_t p = it * ppw + threadIdx.x / tpp;
     const int cvi = threadIdx.x % tpp;
     const bool active = (p < npix) && (cvi < vpr);
@@ -298,6 +299,162 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(const T* __restrict__ D
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 / rank-4 specialisation of the smoothing backward (the hot configuration): same math as smooth_bwd_kernel, but
+//   * the rank contraction w[c] = sum_r B[c][r] A[k][r] runs on packed bf16 pairs (v_dot2c_f32_bf16: two ops instead of
+//     four unpacks + four FMAs), at the pixel itself and at each of the 16 neighbours whose filters read x[p];
+//   * 32-bit element offsets with wave-uniform neighbour strides (no 64-bit per-lane address arithmetic);
+//   * borders are handled branch-free: out-of-image neighbours are redirected to the pixel itself with weight 0.
+// Thread = (pixel, 8 channels); the 8 threads of a pixel are adjacent lanes (tpp = 8, C = 64).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+struct SmPack16 { bf16x8 v; bf2 p[4]; __device__ __forceinline__ void split() { p[0] = __builtin_shufflevector(v, v, 0, 1); p[1] = __builtin_shufflevector(v, v, 2, 3); p[2] = __builtin_shufflevector(v, v, 4, 5); p[3] = __builtin_shufflevector(v, v, 6, 7); } };
+
+__device__ __forceinline__ float sm_dot4(const bf2 (&b)[2], const bf2 (&a)[2]) {
+  return __builtin_amdgcn_fdot2_f32_bf16(b[0], a[0], __builtin_amdgcn_fdot2_f32_bf16(b[1], a[1], 0.f, false), false);
+}
+
+__global__ __launch_bounds__(256, 2) void smooth_bwd_bf16r4_kernel(const bf16* __restrict__ DS, const bf16* __restrict__ X,
+                                                                   const bf16* __restrict__ AS, const bf16* __restrict__ BS,
+                                                                   bf16* __restrict__ DX, bf16* __restrict__ DAL, bf16* __restrict__ DBL,
+                                                                   int B, int H, int W, int dil) {
+  constexpr int K = 2 * ST_ND, R = 4, V = 8, C = 64, VPR = 8;   // 8 threads per pixel == 8 filters: lane cvi keeps filter cvi's dA
+  constexpr int PPW = 256 / VPR;
+  const int npix = B * H * W;
+  const int nloop = (npix + PPW - 1) / PPW;
+  const float third = 1.f / 3.f;
+  for (int it = (int)xcd_remap(blockIdx.x, gridDim.x); it < nloop; it += gridDim.x) {
+    const int p = it * PPW + (int)threadIdx.x / VPR;
+    const int cvi = (int)threadIdx.x % VPR;
+    const bool active = p < npix;
+    const int pc = active ? p : npix - 1;
+    const int c0 = cvi * V;
+    const int x = pc % W, y = (pc / W) % H;
+    // ---- this pixel: softmaxed A [8][4] (packed pairs), B [8 ch][4] (float), ds, x
+    float Bw[V][R];
+    {
+      const bf16* bp = BS + pc * (C * R) + c0 * R;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Vec<bf16>::load(bp + 8 * i, &Bw[2 * i][0]);
+    }
+    float ds[V], ctr[V];
+    Vec<bf16>::load(DS + pc * C + c0, ds);
+    Vec<bf16>::load(X + pc * C + c0, ctr);
+    if (!active) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) ds[e] = 0.f;
+    }
+    // every term carries the tap weight 1/3: accumulate unscaled, scale once at the end
+    float slot[V][R], dx[V], myA[R] = {0.f, 0.f, 0.f, 0.f}, Ak[R] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      dx[e] = 0.f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) slot[e][r] = 0.f;
+    }
+    // Rolled loop over the 8 filters (k = 2 * direction + scale): everything a filter needs is fetched inside its iteration,
+    // so the live state stays ~100 registers and the compiler cannot interleave the 16 neighbour gathers.
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+      const int i = k >> 1, d = (k & 1) ? dil : 1;
+      const int dy = (i == 0) ? 0 : 1;
+      const int dxo = (i == 0) ? 1 : (i == 1) ? 0 : (i == 2) ? 1 : -1;
+      const int dpix = d * (dy * W + dxo);                 // wave-uniform pixel stride of this filter's outer taps
+      bf2 ak[2];                                           // softmaxed A[p][k][0..3]
+      {
+        const bf2* akp = reinterpret_cast<const bf2*>(AS + pc * (K * R) + k * R);
+        ak[0] = akp[0]; ak[1] = akp[1];
+      }
+      const float Af[R] = {(float)ak[0][0], (float)ak[0][1], (float)ak[1][0], (float)ak[1][1]};
+      float f[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) f[e] = ctr[e];
+#pragma unroll
+      for (int sgn = -1; sgn <= 1; sgn += 2) {
+        const int qy = y + sgn * d * dy, qx = x + sgn * d * dxo;
+        const bool inb = (unsigned)qy < (unsigned)H && (unsigned)qx < (unsigned)W;
+        const int q = inb ? pc + sgn * dpix : pc;
+        const float xm = inb ? 1.f : 0.f;
+        // (1) x[q] feeds this pixel's filter k (zero padding outside the image)
+        float xv[V];
+        Vec<bf16>::load(X + q * C + c0, xv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) f[e] = fmaf(xm, xv[e], f[e]);
+        // (2) pixel q's filter k read x[p]:  dx[p] += w_k[q] * ds[q]
+        float dq[V];
+        Vec<bf16>::load(DS + q * C + c0, dq);
+        bf2 aq[2];
+        {
+          const bf2* aqp = reinterpret_cast<const bf2*>(AS + q * (K * R) + k * R);
+          aq[0] = aqp[0]; aq[1] = aqp[1];
+        }
+        const bf16x8* bq = reinterpret_cast<const bf16x8*>(BS + q * (C * R) + c0 * R);
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+          SmPack16 u; u.v = bq[i2]; u.split();
+          const bf2 b0[2] = {u.p[0], u.p[1]}, b1[2] = {u.p[2], u.p[3]};
+          dx[2 * i2] = fmaf(sm_dot4(b0, aq), xm * dq[2 * i2], dx[2 * i2]);
+          dx[2 * i2 + 1] = fmaf(sm_dot4(b1, aq), xm * dq[2 * i2 + 1], dx[2 * i2 + 1]);
+        }
+      }
+      float dAk[R] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float g = ds[e] * f[e];
+        float w = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          slot[e][r] = fmaf(Af[r], f[e], slot[e][r]);
+          dAk[r] = fmaf(Bw[e][r], g, dAk[r]);
+          w = fmaf(Bw[e][r], Af[r], w);
+        }
+        dx[e] = fmaf(w, ds[e], dx[e]);                       // centre tap of this pixel's own filter
+      }
+      // reduce filter k's dA over the pixel's 8 channel threads; lane cvi == k keeps it (and its A[k][:])
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int off = 1; off < VPR; off <<= 1) dAk[r] += __shfl_xor(dAk[r], off, 64);
+        myA[r] = (cvi == k) ? dAk[r] : myA[r];
+        Ak[r] = (cvi == k) ? Af[r] : Ak[r];
+      }
+    }
+    // ---- d b_logit (softmax over r backward), dx
+    if (active) {
+      float ob[V * R];
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        float dot = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { slot[e][r] *= third * ds[e]; dot = fmaf(Bw[e][r], slot[e][r], dot); }
+#pragma unroll
+        for (int r = 0; r < R; ++r) ob[e * R + r] = Bw[e][r] * (slot[e][r] - dot);
+        dx[e] *= third;
+      }
+      bf16* dbp = DBL + p * (C * R) + c0 * R;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Vec<bf16>::store(dbp + 8 * i, ob + 8 * i);
+      Vec<bf16>::store(DX + p * C + c0, dx);
+    }
+    // ---- d a_logit: softmax-over-k backward; lane cvi holds filter k = cvi:  dA_logit[k][r] = A[k][r] (dA[k][r] - sum_k' A dA)
+    {
+      float prod[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        myA[r] *= third;
+        prod[r] = Ak[r] * myA[r];
+#pragma unroll
+        for (int off = 1; off < VPR; off <<= 1) prod[r] += __shfl_xor(prod[r], off, 64);
+      }
+      if (active) {
+        bf16x4 o = {(bf16)(Ak[0] * (myA[0] - prod[0])), (bf16)(Ak[1] * (myA[1] - prod[1])), (bf16)(Ak[2] * (myA[2] - prod[2])),
+                    (bf16)(Ak[3] * (myA[3] - prod[3]))};
+        *reinterpret_cast<bf16x4*>(DAL + p * (K * R) + cvi * R) = o;
+      }
+    }
+  }
+}
+
 static int st_tpp(int vpr) { int t = 1; while (t < vpr) t <<= 1; return t; }
 static unsigned st_grid(int64_t n) { int64_t g = (n + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1; return (unsigned)g; }
 
@@ -310,6 +467,15 @@ static int smooth_dispatch(bool fwd, const void* a0, const void* a1, const void*
   const int64_t npix = (int64_t)B * H * W;
   int64_t grid = (npix + ppw - 1) / ppw;
   if (grid > 8192) grid = 8192;
+  if constexpr (sizeof(T) == 2 && V == 8) {
+    if (!fwd && R == 4 && C == 64 && npix * (int64_t)C * R < ((int64_t)1 << 31)) {
+      int64_t g2 = (npix + 31) / 32;
+      if (g2 > 16384) g2 = 16384;
+      FRL_LAUNCH(smooth_bwd_bf16r4_kernel, dim3((unsigned)g2), dim3(256), 0, st, (const bf16*)a0, (const bf16*)a1, (const bf16*)a2,
+                 (const bf16*)a3, (bf16*)o0, (bf16*)o1, (bf16*)o2, B, H, W, dil);
+      return frl_check_launch("edge_smooth_stencil_bwd");
+    }
+  }
 #define SM_CASE(RR)                                                                                                     \
   if (R == RR) {                                                                                                        \
     if (fwd) FRL_LAUNCH((smooth_fwd_kernel<T, V, RR>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)a0, (const T*)a1, \
