@@ -455,6 +455,112 @@ __global__ __launch_bounds__(256, 2) void smooth_bwd_bf16r4_kernel(const bf16* _
   }
 }
 
+// bf16 / rank-4 / 64-channel forward: thread = (pixel, 8 channels), the pixel's 8 threads are adjacent lanes.  Lane cvi owns filter
+// k = cvi of the softmax over k (4 exps per lane instead of 32, max / sum by 8-lane shuffles); the filter loop is rolled.
+__global__ __launch_bounds__(256, 4) void smooth_fwd_bf16r4_kernel(const bf16* __restrict__ X, const bf16* __restrict__ AL,
+                                                                   const bf16* __restrict__ BL, bf16* __restrict__ SM, bf16* __restrict__ RES,
+                                                                   bf16* __restrict__ AS, bf16* __restrict__ BS, int B, int H, int W, int dil) {
+  constexpr int K = 2 * ST_ND, R = 4, V = 8, C = 64, VPR = 8, PPW = 256 / VPR;
+  const int npix = B * H * W;
+  const int nloop = (npix + PPW - 1) / PPW;
+  const float third = 1.f / 3.f;
+  const int lane = (int)threadIdx.x & 63;
+  for (int it = (int)xcd_remap(blockIdx.x, gridDim.x); it < nloop; it += gridDim.x) {
+    const int p = it * PPW + (int)threadIdx.x / VPR;
+    const int cvi = (int)threadIdx.x % VPR;
+    const bool active = p < npix;
+    const int pc = active ? p : npix - 1;
+    const int c0 = cvi * V;
+    const int x = pc % W, y = (pc / W) % H;
+    // ---- softmax over k (8 lanes) of A[k = cvi][r]
+    float myA[R];
+    {
+      const bf16x4 a4 = *reinterpret_cast<const bf16x4*>(AL + pc * (K * R) + cvi * R);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float v = (float)a4[r];
+        float m = v;
+#pragma unroll
+        for (int off = 1; off < VPR; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        const float e = __expf(v - m);
+        float ssum = e;
+#pragma unroll
+        for (int off = 1; off < VPR; off <<= 1) ssum += __shfl_xor(ssum, off, 64);
+        myA[r] = e / ssum;
+      }
+      if (active) {
+        bf16x4 o = {(bf16)myA[0], (bf16)myA[1], (bf16)myA[2], (bf16)myA[3]};
+        *reinterpret_cast<bf16x4*>(AS + p * (K * R) + cvi * R) = o;
+      }
+    }
+    // ---- softmax over r for this thread's 8 channels
+    float Bw[V][R];
+    {
+      const bf16* bp = BL + pc * (C * R) + c0 * R;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Vec<bf16>::load(bp + 8 * i, &Bw[2 * i][0]);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float m = fmaxf(fmaxf(Bw[e][0], Bw[e][1]), fmaxf(Bw[e][2], Bw[e][3]));
+        float ssum = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { Bw[e][r] = __expf(Bw[e][r] - m); ssum += Bw[e][r]; }
+        const float inv = 1.f / ssum;
+#pragma unroll
+        for (int r = 0; r < R; ++r) Bw[e][r] *= inv;
+      }
+      if (active) {
+        bf16* bo = BS + p * (C * R) + c0 * R;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Vec<bf16>::store(bo + 8 * i, &Bw[2 * i][0]);
+      }
+    }
+    float ctr[V], sm[V];
+    Vec<bf16>::load(X + pc * C + c0, ctr);
+#pragma unroll
+    for (int e = 0; e < V; ++e) sm[e] = 0.f;
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+      const int i = k >> 1, d = (k & 1) ? dil : 1;
+      const int dy = (i == 0) ? 0 : 1;
+      const int dxo = (i == 0) ? 1 : (i == 1) ? 0 : (i == 2) ? 1 : -1;
+      const int dpix = d * (dy * W + dxo);
+      const int src = (lane & ~7) + k;                     // the lane of this pixel that owns filter k
+      float Af[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) Af[r] = __shfl(myA[r], src, 64);
+      float f[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) f[e] = ctr[e];
+#pragma unroll
+      for (int sgn = -1; sgn <= 1; sgn += 2) {
+        const int qy = y + sgn * d * dy, qx = x + sgn * d * dxo;
+        const bool inb = (unsigned)qy < (unsigned)H && (unsigned)qx < (unsigned)W;
+        const int q = inb ? pc + sgn * dpix : pc;
+        const float xm = inb ? 1.f : 0.f;
+        float xv[V];
+        Vec<bf16>::load(X + q * C + c0, xv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) f[e] = fmaf(xm, xv[e], f[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        float w = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) w = fmaf(Bw[e][r], Af[r], w);
+        sm[e] = fmaf(w, third * f[e], sm[e]);
+      }
+    }
+    if (active) {
+      float res[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) res[e] = ctr[e] - sm[e];
+      Vec<bf16>::store(SM + p * C + c0, sm);
+      Vec<bf16>::store(RES + p * C + c0, res);
+    }
+  }
+}
+
 static int st_tpp(int vpr) { int t = 1; while (t < vpr) t <<= 1; return t; }
 static unsigned st_grid(int64_t n) { int64_t g = (n + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1; return (unsigned)g; }
 
@@ -468,6 +574,13 @@ static int smooth_dispatch(bool fwd, const void* a0, const void* a1, const void*
   int64_t grid = (npix + ppw - 1) / ppw;
   if (grid > 8192) grid = 8192;
   if constexpr (sizeof(T) == 2 && V == 8) {
+    if (fwd && R == 4 && C == 64 && npix * (int64_t)C * R < ((int64_t)1 << 31)) {
+      int64_t g2 = (npix + 31) / 32;
+      if (g2 > 16384) g2 = 16384;
+      FRL_LAUNCH(smooth_fwd_bf16r4_kernel, dim3((unsigned)g2), dim3(256), 0, st, (const bf16*)a0, (const bf16*)a1, (const bf16*)a2,
+                 (bf16*)o0, (bf16*)o1, (bf16*)o2, (bf16*)o3, B, H, W, dil);
+      return frl_check_launch("edge_smooth_stencil_fwd");
+    }
     if (!fwd && R == 4 && C == 64 && npix * (int64_t)C * R < ((int64_t)1 << 31)) {
       int64_t g2 = (npix + 31) / 32;
       if (g2 > 16384) g2 = 16384;
