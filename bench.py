@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-finite-check", action="store_true")
+    ap.add_argument("--torch-optimizer", action="store_true", help="A/B: clip_grad_norm_ + torch.optim.AdamW instead of the two HIP launches")
     return ap.parse_args()
 
 
@@ -104,7 +105,7 @@ def main():
                   type_encoder_dropout=0.0, phase_tcn_dropout=0.0, compute_dtype=dtype).to(dev)
     with torch.no_grad():   # well-separated codebook so that all codes are used
         model.quant.codebook.copy_(torch.randn(args.codebook, args.emb_dim, generator=torch.Generator().manual_seed(7)))
-    trainer = VQVAETrainer(model, lr=1e-4, total_steps=10000, check_finite=not args.no_finite_check)
+    trainer = VQVAETrainer(model, lr=1e-4, total_steps=10000, check_finite=not args.no_finite_check, fused_optimizer=not args.torch_optimizer)
     stream = SyntheticTileStream(args.batch, args.time, args.size, args.features, device=dev, dtype=dtype, seed=1234 + rank)
 
     def barrier():

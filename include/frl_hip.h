@@ -133,6 +133,24 @@ int frl_tcn_hot_bwd(const void* x, const void* dy, const float* conv_w, const fl
                     float* d_gn_w, float* d_gn_b, float* d_gate_w, float* d_gate_b, int64_t npix, int HW, int dilation,
                     float eps, void* ws, size_t ws_bytes, frl_stream_t stream);
 
+/* ---- optimizer step (frl/training/representation/step.py:1081-1087: clip_grad_norm_(1.0) then AdamW.step()) ---------------
+ * Two launches for the whole parameter set.  desc: HOST table of ntensors records {float* p; const float* g; float* m; float* v;
+ * int64_t n; float weight_decay; int lag} (48 bytes; lag = updates the tensor skipped) -- it travels in the kernel-argument
+ * segment, so moved gradient buffers cost no copy or sync; chunks: DEVICE table of nchunks int32 pairs {tensor index,
+ * 4096-element window} sorted by tensor, chunk_tensor: its tensor column on the HOST.  step is the 1-based update count (bias
+ * corrections in float64 as torch.optim.AdamW); max_norm <= 0 disables clipping; norm_out (device float, may be NULL) receives
+ * the pre-clip global gradient norm.  ok (device float, may be NULL): the reference's isfinite guard evaluated ON THE DEVICE --
+ * ok[0] <= 0 leaves parameters and moments untouched; counters (device int[2], may be NULL) = {updates applied, updates skipped},
+ * and when given, counters[0] + 1 replaces `step` as the update number (exact under skipped batches, no host sync). */
+size_t frl_adamw_workspace_bytes(void);
+int frl_adamw_clip_step(const void* desc_host, int ntensors, const void* chunks, const int* chunk_tensor, int nchunks, float max_norm,
+                        float lr, double beta1, double beta2, float eps, int step, float* norm_out, const float* ok, int* counters,
+                        void* ws, size_t ws_bytes, frl_stream_t stream);
+/* dst[i] = scale * src[i] over a HOST table of {const float* src; float* dst; int64_t n} records (24 bytes; src NULL -> zeros):
+ * flattens the scattered gradients of a bucket for the data-parallel all-reduce in one launch. */
+int frl_multi_tensor_scale_copy(const void* desc_host, int ntensors, const void* chunks, const int* chunk_tensor, int nchunks, float scale,
+                                frl_stream_t stream);
+
 /* ---- FiLM modulation, time mean, add ---------------------------------------------------------------------------
  * z = gamma * h + beta broadcast over T (frl/models/representation.py:369-372); h [B][T][HW][C], gamma [B][HW][C]. */
 int frl_film_modulate_fwd(const void* h, const void* gamma, const void* beta, void* out, int64_t B, int T, int64_t HW,

@@ -154,3 +154,35 @@ def test_vq_bwd_and_ema(dtype):
     assert (ec.cpu().double() - c_ref).abs().max().item() <= 1e-5 * c_ref.abs().max().item()
     assert (es.cpu().double() - s_ref).abs().max().item() <= 1e-5 * s_ref.abs().max().item()
     assert (cb.cpu().double() - cb_ref).abs().max().item() <= 1e-4 * cb_ref.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_hip_adamw_clip_matches_torch():
+    """csrc/optim.hip (two launches) vs clip_grad_norm_ + torch.optim.AdamW over 4 steps, incl. a parameter without gradient."""
+    from frl_hip.training.optim import HipAdamW
+    DEV = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 64, 3), (64,), (512, 64), (5000,), (12, 64, 1, 1), (7,)]
+    ref = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+    dev = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ref]
+    groups = lambda ps: [{"params": ps[:2] + ps[3:], "weight_decay": 0.01}, {"params": [ps[2]], "weight_decay": 0.0}]
+    o_ref = torch.optim.AdamW(groups(ref), lr=3e-3, betas=(0.9, 0.95))
+    o_dev = HipAdamW(groups(dev), lr=3e-3, betas=(0.9, 0.95))
+    order = [0, 1, 3, 4, 5, 2]                                  # HipAdamW keeps group order
+    for step in range(4):
+        scale = [5.0, 0.01, 1.0, 30.0][step]                     # clip active / inactive
+        for i, (pr, pd) in enumerate(zip(ref, dev)):
+            if i == 5 and step % 2 == 1:
+                pr.grad, pd.grad = None, None                    # parameter unused this step
+                continue
+            gr = torch.randn(*shapes[i], generator=g) * scale
+            pr.grad, pd.grad = gr.clone(), gr.clone().to(DEV)
+        for grp_r, grp_d in zip(o_ref.param_groups, o_dev.param_groups):
+            grp_r["lr"] = grp_d["lr"] = 3e-3 * (1.0 - 0.1 * step)
+        n_ref = torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        o_ref.step()
+        n_dev = o_dev.step(1.0)
+        assert abs(n_dev.item() - n_ref.item()) <= 1e-5 * n_ref.item()
+        for pr, pd in zip(ref, dev):
+            assert (pd.detach().cpu() - pr.detach()).abs().max().item() <= 2e-6
+    assert [dev[i] is p for i, p in zip(order, o_dev.params)] == [True] * 6

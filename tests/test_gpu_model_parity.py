@@ -153,6 +153,54 @@ def test_three_step_loss_trajectory_matches_oracle(golden_dir):
     assert np.abs(np.asarray(traj) - fx["traj"]).max() < 2e-5, (traj, fx["traj"])
 
 
+def test_single_rank_rccl_reducer_path_matches_plain_trainer(golden_dir):
+    """The data-parallel path on ONE rank (RCCL communicator of size 1, hooks forced): gradients flow through the multi-tensor
+    pack -> flat buckets -> HipAdamW-in-place route and must reproduce the plain trainer's loss trajectory exactly."""
+    import torch.distributed as dist
+    from frl_hip.parallel import BucketedGradAllReduce
+    from frl_hip.training.trainer import VQVAETrainer
+    fx = _load(golden_dir, "vqvae_tiny_seed0")
+    tiles = torch.from_numpy(fx["tiles"]).float().to(DEV)
+    plain = VQVAETrainer(_vqvae_from_fixture(fx), lr=1e-3, total_steps=10)
+    ref = [plain.step(tiles[i])["loss"].item() for i in range(3)]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29731", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        m = _vqvae_from_fixture(fx)
+        tr = VQVAETrainer(m, lr=1e-3, total_steps=10)
+        tr.reducer = BucketedGradAllReduce([(n, p) for n, p in m.named_parameters() if p.requires_grad], force_hooks=True)
+        assert tr.reducer.active and tr.hip_opt
+        got = [tr.step(tiles[i])["loss"].item() for i in range(3)]
+    finally:
+        dist.destroy_process_group()
+    assert got == ref, (got, ref)
+
+
+def test_nonfinite_batch_is_skipped_on_device(golden_dir):
+    """step.py:1057-1074 semantics without a host sync: a non-finite loss leaves parameters, moments and the update count untouched."""
+    from frl_hip.training.trainer import VQVAETrainer
+    fx = _load(golden_dir, "vqvae_tiny_seed0")
+    m = _vqvae_from_fixture(fx)
+    tr = VQVAETrainer(m, lr=1e-3, total_steps=10)
+    tiles = torch.from_numpy(fx["tiles"]).float().to(DEV)
+    tr.step(tiles[0])
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    bad = tiles[1].clone()
+    bad[0, 0, 0, 0, 0] = float("nan")
+    out = tr.step(bad)
+    assert not torch.isfinite(out["loss"]).item()
+    for n, p in m.named_parameters():
+        assert torch.equal(p.detach(), before[n]), n
+    assert tr.opt.applied_and_skipped == (1, 1) and tr.n_skipped == 1
+    l2 = tr.step(tiles[1])["loss"].item()                      # training continues; the update count did not advance on the bad batch
+    assert np.isfinite(l2) and tr.opt.applied_and_skipped == (2, 1)
+    ref = VQVAETrainer(_vqvae_from_fixture(fx), lr=1e-3, total_steps=10)
+    ref.step(tiles[0])
+    ref.step_idx += 1                                          # the LR schedule advances per batch, skipped or not
+    assert abs(ref.step(tiles[1])["loss"].item() - l2) < 1e-6
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.model.named_parameters()):
+        assert (p - q).abs().max().item() <= 1e-6, n
+
+
 def test_bf16_mode_tracks_oracle_and_indices_are_exact(golden_dir):
     """Performance mode: bf16 storage cannot meet 1e-5; check agreement at bf16 resolution and that the VQ indices are the
     exact float64 argmin of the bf16 latents the encoder actually produced."""

@@ -119,7 +119,7 @@ template <typename T, int NF>
 static int launch_pw(const void* x, const void* xmask, int mask_act, const float* w, int64_t so, int64_t si,
                      const float* bias, void* y, int64_t P, int Cin, int Cout, int act, void* ws, size_t ws_bytes, hipStream_t st) {
   typedef typename DT<T>::frag_t frag_t;
-  constexpr int NT = 2;
+  constexpr int NT = 1;
   const int MB = (Cout + 15) / 16;
   const size_t lds = (size_t)MB * NF * 64 * sizeof(frag_t);
   if (lds > 160 * 1024) return frl_fail(-3, "pw_conv: weights exceed LDS (Cin*Cout too large)");
@@ -129,7 +129,7 @@ static int launch_pw(const void* x, const void* xmask, int mask_act, const float
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t ngroups = ((P + 15) / 16 + NT - 1) / NT;
   int64_t grid = (ngroups + 3) / 4;
-  if (grid > 2048) grid = 2048;
+  if (grid > 4096) grid = 4096;
   if (grid < 1) grid = 1;
   FRL_LAUNCH(kern, dim3((unsigned)grid), dim3(256), lds, st, (const T*)x, (const T*)xmask, mask_act,
              (const frag_t*)ws, bias, (T*)y, P, Cin, Cout, act);

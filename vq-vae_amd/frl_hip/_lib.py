@@ -23,7 +23,7 @@ class FrlHipError(RuntimeError):
 
 
 # name -> (restype, argtypes); kept in sync with include/frl_hip.h (tests check every symbol resolves)
-P, I, L, F, S = c_void_p, c_int, c_int64, c_float, c_size_t
+P, I, L, F, S, D = c_void_p, c_int, c_int64, c_float, c_size_t, ctypes.c_double
 SIGNATURES = {
     "frl_version": (c_int, []),
     "frl_last_error": (c_char_p, []),
@@ -68,6 +68,9 @@ SIGNATURES = {
     "frl_tcn_block_bwd_fused_supported": (c_int, [I, I, I, I, I, I]),
     "frl_tcn_block_bwd_fused_workspace_bytes": (S, [L]),
     "frl_tcn_block_bwd_fused": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, F, P, S, P]),
+    "frl_adamw_workspace_bytes": (S, []),
+    "frl_adamw_clip_step": (c_int, [P, I, P, P, I, F, F, D, D, F, I, P, P, P, P, S, P]),
+    "frl_multi_tensor_scale_copy": (c_int, [P, I, P, P, I, F, P]),
     "frl_tcn_hot_supported": (c_int, [I, I, I, I, I, I, I]),
     "frl_tcn_hot_fwd_workspace_bytes": (S, []),
     "frl_tcn_hot_bwd_workspace_bytes": (S, [L]),

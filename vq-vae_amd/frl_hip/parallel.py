@@ -11,13 +11,16 @@ from __future__ import annotations
 
 from typing import Dict, List, Sequence
 
+import ctypes
+import struct
+
 import torch
 import torch.distributed as dist
 
 
 class BucketedGradAllReduce:
     def __init__(self, named_params: Sequence, late_prefixes: Sequence[str] = ("encoder.", "spatial_conv."),
-                 process_group=None):
+                 process_group=None, force_hooks: bool = False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         params = [(n, p) for n, p in named_params if p.requires_grad]
@@ -36,11 +39,18 @@ class BucketedGradAllReduce:
                 self._index[id(p)] = bi
         self.comm_stream = torch.cuda.Stream() if (self.buckets and self.buckets[0][0].is_cuda) else None
         self._hooks = []
-        if self.world > 1:
+        self._tables: Dict[int, tuple] = {}                 # bucket -> (gradient pointer key, device desc table, device chunk table)
+        self.on_gpu = bool(self.buckets) and self.buckets[0][0].is_cuda
+        if self.world > 1 or force_hooks:
             for bucket in self.buckets:
                 for p in bucket:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.reset()
+
+    @property
+    def active(self) -> bool:
+        """True when gradients pass through the flat buckets (world > 1, or hooks forced for single-rank testing)."""
+        return bool(self._hooks)
 
     def reset(self):
         self._pending = {bi: len(b) for bi, b in enumerate(self.buckets)}
@@ -61,27 +71,73 @@ class BucketedGradAllReduce:
         else:
             ctx = _Null()
         with ctx:
+            if self.on_gpu:
+                self._pack_gpu(bi)                         # ONE launch: flat = grads / world  (csrc/optim.hip)
+            else:
+                off = 0
+                for p in bucket:
+                    n = p.numel()
+                    g = p.grad if p.grad is not None else torch.zeros_like(p)
+                    flat[off:off + n].copy_(g.reshape(-1))
+                    off += n
+                flat.div_(self.world)
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if self.world > 1 else None
+        self._works.append((bi, work))
+
+    def _pack_gpu(self, bi: int):
+        from . import _lib
+        from .ops import check
+        from .training.optim import ChunkTable
+        bucket, flat = self.buckets[bi], self._flat[bi]
+        grads = []
+        for p in bucket:
+            g = p.grad
+            if g is not None and not (g.dtype == torch.float32 and g.is_contiguous()):
+                g = g.float().contiguous()
+            grads.append(g)
+        self._keep = getattr(self, "_keep", {})
+        self._keep[bi] = grads
+        key = tuple(g.data_ptr() if g is not None else 0 for g in grads)
+        tab = self._tables.get(bi)
+        if tab is None or tab[0] != key:
+            off, recs = 0, []
+            for p, g in zip(bucket, grads):
+                recs.append(struct.pack("<QQq", g.data_ptr() if g is not None else 0, flat.data_ptr() + 4 * off, p.numel()))
+                off += p.numel()
+            raw = b"".join(recs)
+            chunks = tab[2] if tab is not None else ChunkTable([p.numel() for p in bucket], flat.device)
+            tab = (key, ctypes.create_string_buffer(raw, len(raw)), chunks)
+            self._tables[bi] = tab
+        check(_lib.load().frl_multi_tensor_scale_copy(ctypes.cast(tab[1], ctypes.c_void_p), len(bucket), ctypes.c_void_p(tab[2].dev.data_ptr()),
+                                                      ctypes.cast(tab[2].host_tensor_col, ctypes.c_void_p), tab[2].n, 1.0 / self.world,
+                                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "frl_multi_tensor_scale_copy")
+
+    def flat_grads(self) -> Dict[int, torch.Tensor]:
+        """id(param) -> view of its averaged gradient inside the flat bucket (valid after finish(scatter=False))."""
+        out = {}
+        for bi, bucket in enumerate(self.buckets):
             off = 0
             for p in bucket:
                 n = p.numel()
-                g = p.grad if p.grad is not None else torch.zeros_like(p)
-                flat[off:off + n].copy_(g.reshape(-1))
+                out[id(p)] = self._flat[bi][off:off + n].view_as(p)
                 off += n
-            flat.div_(self.world)
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._works.append((bi, work))
+        return out
 
-    def finish(self):
-        """Waits for the collectives and scatters the averaged gradients back into p.grad.  Call after backward()."""
-        if self.world <= 1:
+    def finish(self, scatter: bool = True):
+        """Waits for the collectives; with scatter=True the averaged gradients are copied back into p.grad, with scatter=False
+        they stay in the flat buckets (flat_grads()) for an optimizer that reads them in place.  Call after backward()."""
+        if self.world <= 1 and not self._hooks:
             return
         for bi, pend in self._pending.items():
             if pend != 0:          # parameters that received no gradient this step (unused branch)
                 self._launch(bi)
         for bi, work in self._works:
-            work.wait()
+            if work is not None:
+                work.wait()
             if self.comm_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
+            if not scatter:
+                continue
             off = 0
             for p in self.buckets[bi]:
                 n = p.numel()

@@ -28,7 +28,12 @@ class VQVAETrainer:
         if cb:
             groups.append({"params": cb, "weight_decay": 0.0})
         on_gpu = bool(rest) and rest[0].is_cuda
-        self.opt = torch.optim.AdamW(groups, lr=lr, betas=betas, fused=(fused_optimizer and on_gpu))
+        self.hip_opt = bool(fused_optimizer and on_gpu)
+        if self.hip_opt:                                   # clip + AdamW in two HIP launches (csrc/optim.hip)
+            from .optim import HipAdamW
+            self.opt = HipAdamW(groups, lr=lr, betas=betas)
+        else:
+            self.opt = torch.optim.AdamW(groups, lr=lr, betas=betas)
         self.params = [p for _, p in named]
         self.lr, self.min_lr, self.total_steps, self.max_norm = lr, min_lr, total_steps, max_norm
         self.check_finite = check_finite
@@ -37,6 +42,11 @@ class VQVAETrainer:
         self.epoch = 0
         self.skipped = 0
         self.reducer = BucketedGradAllReduce(named) if (dist.is_available() and dist.is_initialized()) else None
+
+    @property
+    def n_skipped(self) -> int:
+        """Batches skipped by the isfinite guard (reads the device counter when the HIP optimizer is in use)."""
+        return self.opt.applied_and_skipped[1] if self.hip_opt else self.skipped
 
     def set_epoch(self, epoch: int):
         """Per-epoch curricula: beta schedule of configs/vae_v0.yaml:21-27."""
@@ -58,16 +68,31 @@ class VQVAETrainer:
         self.opt.zero_grad(set_to_none=True)
         out = self.model.forward_tiles(tile, mask)
         loss = out["loss"]
-        if self.check_finite and not self._all_finite(loss):
-            self.skipped += 1                     # step.py:1057-1074: skip the batch, keep training
-            if self.reducer is not None:
-                self.reducer.reset()
-            return out
+        ok = None
+        if self.check_finite:
+            if self.hip_opt:
+                # step.py:1057-1074 (skip the batch on a non-finite loss) evaluated on the device: the flag gates the optimizer
+                # kernels, so the host never waits for the loss and keeps queueing the next step
+                ok = torch.isfinite(loss.detach()).float().reshape(1)
+                if self.reducer is not None and self.reducer.world > 1:
+                    dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank takes the same decision
+            elif not self._all_finite(loss):
+                self.skipped += 1
+                if self.reducer is not None:
+                    self.reducer.reset()
+                return out
         loss.backward()
         if self.reducer is not None:
-            self.reducer.finish()
-        out["grad_norm"] = torch.nn.utils.clip_grad_norm_(self.params, self.max_norm)
-        self.opt.step()
+            self.reducer.finish(scatter=not self.hip_opt)   # HipAdamW reads the flat buckets in place
+        if self.hip_opt:
+            grads = None
+            if self.reducer is not None and self.reducer.active:   # averaged gradients are read straight from the all-reduce buckets
+                fg = self.reducer.flat_grads()
+                grads = [fg[id(p)] for p in self.opt.params]
+            out["grad_norm"] = self.opt.step(self.max_norm, grads, ok)
+        else:
+            out["grad_norm"] = torch.nn.utils.clip_grad_norm_(self.params, self.max_norm)
+            self.opt.step()
         self.step_idx += 1
         out["lr"] = lr_now
         return out
