@@ -87,7 +87,9 @@ def _vq_case(N, K, d, dtype, seed, ties=False):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("N,K,d,ties", [(4096, 256, 64, True), (1000, 16, 8, True), (8192, 512, 64, False),
                                         (2048, 1024, 64, False), (2048, 640, 128, False), (777, 100, 12, True),
-                                        (64, 16, 4, False)])
+                                        (64, 16, 4, False),
+                                        # >= 65536 rows with d <= 64: 16-wave workgroups (one codebook copy per CU), chunks up to 1024 codes
+                                        (65536 + 123, 512, 64, True), (66000, 1024, 64, False), (65600, 1100, 64, False), (65536, 256, 32, True)])
 def test_vq_assign_bit_exact(dtype, N, K, d, ties):
     from frl_hip import ops
     dev = _dev()

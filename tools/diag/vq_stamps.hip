@@ -1,0 +1,33 @@
+// Diagnostic harness: phase stamps of the VQ assignment kernel (16-wave variant) on BASELINE configs[1] sizes.
+#define VQ_STAMPS 1
+#include "../../vq-vae_amd/csrc/vq.hip"
+#include "../../vq-vae_amd/csrc/frl_host.hip"
+#include <vector>
+#include <random>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+int main(int argc, char** argv) {
+  const int64_t N = 262144; const int K = argc > 1 ? atoi(argv[1]) : 512, d = 64;
+  std::mt19937 rng(7); std::normal_distribution<float> nd(0.f, 1.f);
+  std::vector<bf16> hz(N * d); for (auto& v : hz) v = (bf16)nd(rng);
+  std::vector<float> he((size_t)K * d); for (auto& v : he) v = nd(rng);
+  bf16 *z, *zq; float *E, *stats; int32_t *idx, *counts; void* ws; unsigned long long* dbg;
+  CK(hipMalloc(&z, N * d * 2)); CK(hipMalloc(&zq, N * d * 2)); CK(hipMalloc(&E, K * d * 4)); CK(hipMalloc(&stats, 64)); CK(hipMalloc(&idx, N * 4));
+  CK(hipMalloc(&counts, K * 4));
+  CK(hipMemcpy(z, hz.data(), N * d * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(E, he.data(), (size_t)K * d * 4, hipMemcpyHostToDevice));
+  const size_t wsb = frl_vq_workspace_bytes(N, K, d); CK(hipMalloc(&ws, wsb));
+  CK(hipMalloc(&dbg, 512 * 128 * 8)); CK(hipMemset(dbg, 0, 512 * 128 * 8));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(vq_dbg), &dbg, sizeof(dbg)));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int it = 0; it < 4; ++it) {
+    CK(hipEventRecord(e0, 0));
+    int rc = frl_vq_assign_fwd(z, E, N, K, d, idx, zq, stats, counts, FRL_BF16, ws, wsb, 0);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); printf("iter %d rc=%d %.1f us (whole frl_vq_assign_fwd)\n", it, rc, ms * 1e3f);
+  }
+  std::vector<unsigned long long> h(512 * 128); CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+  const char* nm[6] = {"z load + norms", "batch bias (3 barriers)", "chunk/en fill (2 barriers)", "main loop", "epilogue", "tail"};
+  double tot = 0;
+  for (int ph = 0; ph < 6; ++ph) { double s = 0; int nz = 0; for (int b = 0; b < 512; ++b) for (int w = 0; w < 16; ++w) { const double v = (double)h[(size_t)b * 128 + w * 8 + ph]; s += v; nz += h[(size_t)b * 128 + w * 8 + 3] != 0; } s /= nz; tot += s; printf("phase %d %-28s %9.0f cycles per wave (whole kernel)\n", ph, nm[ph], s); }
+  printf("total %.0f cycles per wave\n", tot);
+  return 0;
+}

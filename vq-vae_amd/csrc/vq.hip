@@ -74,8 +74,13 @@ __global__ void vq_pack_kernel(const float* __restrict__ E, int K, int d, typena
 // ---------------------------------------------------------------------------------------------
 // main assignment kernel
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NF, int NT>
-__global__ __launch_bounds__(256) void vq_assign_kernel(
+// NW = waves per workgroup: 16 (one workgroup per CU, ONE LDS copy of the codebook chunk shared by four waves per SIMD) when the
+// batch is large enough, else 4.
+#ifdef VQ_STAMPS
+__device__ unsigned long long* vq_dbg;      // diagnostic build only (tools/diag/vq_stamps.hip)
+#endif
+template <typename T, int NF, int NT, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
     const T* __restrict__ Z, const float* __restrict__ E, const float* __restrict__ en_g, const VqHeader* __restrict__ hdr,
     int64_t N, int K, int d, int Kc, int32_t* __restrict__ idx_out, T* __restrict__ zq_out,
     float* __restrict__ partial /*[grid*4]*/, int32_t* __restrict__ hist_slab /*[grid][K]*/, VqHeader* __restrict__ hdr_w,
@@ -96,14 +101,22 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(
   const float err_rel = (float)(4 * q + 8) * 1.1920929e-7f;            // (d_pad+8) * 2^-23: f32 accumulation of exact products
   const float thr_rel = 3.0517578125e-5f + 2.f * err_rel;              // 2^-(22-7) key truncation of both scores + 2*err
 
-  for (int k = tid; k < K; k += 256) hist[k] = 0;
+#ifdef VQ_STAMPS
+  __shared__ unsigned long long vq_ts[16][8];
+  if (tid < 128) (&vq_ts[0][0])[tid] = 0ull;
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#define VQ_ST(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); if (lane == 0) vq_ts[wave][i] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define VQ_ST(i) do { } while (0)
+#endif
+  for (int k = tid; k < K; k += NW * 64) hist[k] = 0;
   float sq_acc = 0.f;
   int filled_chunk = -1;
 
-  const int64_t vec_per_batch = 4 * NT * 16;
+  const int64_t vec_per_batch = NW * NT * 16;
   const int64_t nbatch = (N + vec_per_batch - 1) / vec_per_batch;
   for (int64_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
-    const int64_t v0 = (batch * 4 + wave) * (NT * 16);
+    const int64_t v0 = (batch * NW + wave) * (NT * 16);
     LQTile<T, NF> zt[NT];
     float thr[NT];
     unsigned g1[NT], g2[NT];
@@ -124,16 +137,21 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(
       zmax = fmaxf(zmax, zn);
       g1[t] = 0xFFFFFFFFu; g2[t] = 0xFFFFFFFFu; gc[t] = 0;
     }
+    VQ_ST(0);                                                    // z loads issued + norms (includes the load latency)
     // One positive bias per workgroup batch (max ||z||^2 of its 256 vectors, + margin) is folded into the LDS copy of
     // ||e||^2, so the MFMA accumulator is initialised straight from LDS and every score en + Cb - 2 z.e stays > 0.
-    __syncthreads();
-    if (tid == 0) *cbw = 0u;
-    __syncthreads();
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, off, 64));
-    if (lane == 0) atomicMax(cbw, __float_as_uint(zmax));
+    __syncthreads();                                             // previous batch is done with enl / the slots
+    if (lane == 0) cbw[wave] = __float_as_uint(zmax);
     __syncthreads();
-    const float zbm = __uint_as_float(*cbw);
+    {
+      unsigned m = 0u;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) m = m > cbw[w] ? m : cbw[w];
+      cbw[NW] = m;                                               // same value from every thread (benign)
+    }
+    const float zbm = __uint_as_float(cbw[NW]);
     const float Cb = zbm + 9.765625e-4f * (zbm + enmax) + 1e-30f;     // + 2^-10 (zmax + enmax)
     {
       const float sroot = sqrtf(zbm) + sqrtf(enmax);
@@ -141,15 +159,17 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(
 #pragma unroll
       for (int t = 0; t < NT; ++t) thr[t] = tv;
     }
+    VQ_ST(1);                                                    // batch bias: 3 barriers + LDS atomic max
     for (int c = 0; c < nchunks; ++c) {
       {
         __syncthreads();
         const int kbase = c * Kc;
-        if (filled_chunk != c) copy_frags_lds<T>(wl, pk + (size_t)(kbase / 16) * NF * 64, (Kc / 16) * NF * 64, tid, 256);
-        for (int i = tid; i < Kc; i += 256) enl[i] = (kbase + i < K) ? en_g[kbase + i] + Cb : 3.0e38f;
+        if (filled_chunk != c) copy_frags_lds<T>(wl, pk + (size_t)(kbase / 16) * NF * 64, (Kc / 16) * NF * 64, tid, NW * 64);
+        for (int i = tid; i < Kc; i += NW * 64) enl[i] = (kbase + i < K) ? en_g[kbase + i] + Cb : 3.0e38f;
         __syncthreads();
         filled_chunk = c;
       }
+      VQ_ST(2);                                                  // codebook chunk / ||e||^2 fill
       const int nmb = Kc / 16;
       for (int g0 = 0; g0 < nmb; g0 += 8) {
         unsigned c1[NT], c2[NT];
@@ -185,6 +205,7 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(
         }
       }
     }
+    VQ_ST(3);                                                    // MFMA + key/min/med3 main loop
     // ---- wave-level min-reduce over the 4 lane groups that share a vector ----
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -239,12 +260,18 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(
         }
       }
     }
+    VQ_ST(4);                                                    // reduce, ambiguity test, z_q gather / store, histogram
   }
   // ---- per-workgroup outputs: 4 wave partials of the squared error, histogram slab ----
   const float ws_ = wave_sum(sq_acc);
-  if (lane == 0) partial[blockIdx.x * 4 + wave] = ws_;
+  if (lane == 0) partial[blockIdx.x * NW + wave] = ws_;
   __syncthreads();
-  for (int k = tid; k < K; k += 256) hist_slab[(int64_t)blockIdx.x * K + k] = hist[k];
+  for (int k = tid; k < K; k += NW * 64) hist_slab[(int64_t)blockIdx.x * K + k] = hist[k];
+#ifdef VQ_STAMPS
+  VQ_ST(5);
+  __syncthreads();
+  if (tid < 128) vq_dbg[(size_t)blockIdx.x * 128 + tid] = (&vq_ts[0][0])[tid];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -338,12 +365,22 @@ __global__ __launch_bounds__(256) void vq_fixup_lds_kernel(const T* __restrict__
   const int namb = hdr->namb;
   if ((int)blockIdx.x * 4 >= namb) return;                  // whole workgroup has no rows: skip the fill
   {
+    // coalesced fill with 8 independent 16-byte loads in flight per thread (one memory latency per 32 KB, not per 4 KB)
     const f32x4* E4 = reinterpret_cast<const f32x4*>(E);
-    for (int i = tid; i < K * d4; i += 256) {
-      const int kk = i / d4, j = (i - kk * d4) * 4;
-      const f32x4 v = E4[i];
-      *reinterpret_cast<f32x4*>(et + kk * pitch + j) =
-          f32x4{to_f32(from_f32<T>(v[0])), to_f32(from_f32<T>(v[1])), to_f32(from_f32<T>(v[2])), to_f32(from_f32<T>(v[3]))};
+    const int nv = K * d4;
+    for (int i0 = tid; i0 < nv; i0 += 256 * 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256; v[u] = i < nv ? E4[i] : f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        if (i < nv) {
+          const int kk = i / d4, j = (i - kk * d4) * 4;
+          *reinterpret_cast<f32x4*>(et + kk * pitch + j) = f32x4{to_f32(from_f32<T>(v[u][0])), to_f32(from_f32<T>(v[u][1])),
+                                                                 to_f32(from_f32<T>(v[u][2])), to_f32(from_f32<T>(v[u][3]))};
+        }
+      }
     }
   }
   __syncthreads();
@@ -688,33 +725,39 @@ __global__ __launch_bounds__(256) void vq_ema_kernel(const float* __restrict__ s
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-static int vq_chunk(int K, int d_pad, size_t esize) {
+static int vq_chunk(int K, int d_pad, size_t esize, int nw) {
+  (void)nw;                                                  // <= 64 KB of codes so that two workgroups fit a CU
+  const size_t cap = 64 * 1024;
   int kc = VQ_MAX_CHUNK;
-  while (kc > 16 && (size_t)kc * d_pad * esize > 64 * 1024) kc >>= 1;
+  while (kc > 16 && (size_t)kc * d_pad * esize > cap) kc >>= 1;
   const int kpad = (K + 15) / 16 * 16;
   if (kc > kpad) kc = kpad;
   return kc;
 }
-static int vq_grid(int64_t N, int NT) {
-  const int64_t nb = (N + 4 * NT * 16 - 1) / (4 * NT * 16);
-  return (int)(nb < 512 ? (nb < 1 ? 1 : nb) : 512);
+// Large batches (d <= 64): 8-wave workgroups, two per CU (four waves per SIMD, two 16-vector tiles per wave inside the 128-register
+// budget); the two workgroups of a CU drift apart, so one streams z / writes z_q while the other is in its MFMA loop.  Else 4 waves x 4 tiles.
+static int vq_waves(int64_t N, int d) { return (d <= 64 && N >= (int64_t)256 * 8 * 2 * 16) ? 8 : 4; }
+static int vq_grid(int64_t N, int d) {
+  const int nw = vq_waves(N, d), NT = nw == 8 ? 2 : 4;
+  const int64_t nb = (N + nw * NT * 16 - 1) / (nw * NT * 16);
+  const int cap = 512;
+  return (int)(nb < cap ? (nb < 1 ? 1 : nb) : cap);
 }
-#define VQ_NT 4
 #define VQ_FIX_WAVES 1024
 #define VQ_BWD_WGS 256
 
 struct VqLayout { size_t hdr, en, counts_fix, partial, amb, hist, pack, total; int grid; };
-static VqLayout vq_layout(int64_t N, int K) {
+static VqLayout vq_layout(int64_t N, int K, int d) {
   VqLayout L;
-  L.grid = vq_grid(N, VQ_NT);
+  L.grid = vq_grid(N, d);
   size_t o = 0;
   L.hdr = o; o += 256;
   L.counts_fix = o; o += ((size_t)K * 4 + 255) / 256 * 256;       // [hdr, counts_fix] are zeroed every call
   L.en = o; o += ((size_t)K * 4 + 255) / 256 * 256;
-  L.partial = o; o += ((size_t)L.grid * 4 * 4 + 255) / 256 * 256;
+  L.partial = o; o += ((size_t)L.grid * 16 * 4 + 255) / 256 * 256;
   L.amb = o; o += ((size_t)N * 4 + 255) / 256 * 256;
   L.hist = o; o += ((size_t)L.grid * K * 4 + 255) / 256 * 256;
-  L.pack = o; o += (size_t)((K + 15) / 16 + 32) * 16 * 128 * 4;      // packed codebook, padded to a whole chunk, d_pad <= 128
+  L.pack = o; o += (size_t)((K + 15) / 16 + 64) * 16 * 128 * 4;      // packed codebook, padded to a whole chunk, d_pad <= 128
   L.total = o;
   return L;
 }
@@ -723,9 +766,10 @@ template <typename T, int NF>
 static int launch_vq(const void* z, const float* E, int64_t N, int K, int d, int32_t* idx, void* zq, float* stats,
                      int32_t* counts, char* ws, hipStream_t st) {
   typedef typename DT<T>::frag_t frag_t;
-  const VqLayout L = vq_layout(N, K);
+  const VqLayout L = vq_layout(N, K, d);
   const int d_pad = NF * DT<T>::FE * 4;
-  const int Kc = vq_chunk(K, d_pad, sizeof(T));
+  const int nw = vq_waves(N, d);
+  const int Kc = vq_chunk(K, d_pad, sizeof(T), nw);
   VqHeader* hdr = (VqHeader*)(ws + L.hdr);
   float* en = (float*)(ws + L.en);
   FRL_HIP(hipMemsetAsync(ws, 0, L.en, st));                          // header + counts_fix
@@ -734,12 +778,19 @@ static int launch_vq(const void* z, const float* E, int64_t N, int K, int d, int
   const int npk = (kpadc / 16) * NF * 64;
   frag_t* pk = (frag_t*)(ws + L.pack);
   FRL_LAUNCH((vq_pack_kernel<T, NF>), dim3((npk + 255) / 256), dim3(256), 0, st, E, K, d, pk, npk);
-  const size_t lds = (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc * 4 + (size_t)K * 4 + 16;
+  const size_t lds = (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc * 4 + (size_t)K * 4 + 128;
   if (lds > 160 * 1024) return frl_fail(-3, "vq_assign: LDS budget exceeded (K too large for histogram)");
-  auto kern = vq_assign_kernel<T, NF, VQ_NT>;
-  if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  FRL_LAUNCH(kern, dim3(L.grid), dim3(256), lds, st, (const T*)z, E, en, hdr, N, K, d, Kc, idx, (T*)zq,
-             (float*)(ws + L.partial), (int32_t*)(ws + L.hist), hdr, (int32_t*)(ws + L.amb), (const frag_t*)pk);
+  if (nw == 8) {
+    auto kern = vq_assign_kernel<T, NF, 2, 8>;
+    if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FRL_LAUNCH(kern, dim3(L.grid), dim3(512), lds, st, (const T*)z, E, en, hdr, N, K, d, Kc, idx, (T*)zq,
+               (float*)(ws + L.partial), (int32_t*)(ws + L.hist), hdr, (int32_t*)(ws + L.amb), (const frag_t*)pk);
+  } else {
+    auto kern = vq_assign_kernel<T, NF, 4, 4>;
+    if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FRL_LAUNCH(kern, dim3(L.grid), dim3(256), lds, st, (const T*)z, E, en, hdr, N, K, d, Kc, idx, (T*)zq,
+               (float*)(ws + L.partial), (int32_t*)(ws + L.hist), hdr, (int32_t*)(ws + L.amb), (const frag_t*)pk);
+  }
   const size_t fix_lds = (size_t)4 * (d + 64 * (d + 1)) * sizeof(float);
   {
     auto fk = vq_fixup_kernel<T>;
@@ -749,14 +800,14 @@ static int launch_vq(const void* z, const float* E, int64_t N, int K, int d, int
   if (res_lds <= 150 * 1024 && (d & 3) == 0) {
     auto fk = vq_fixup_lds_kernel<T>;
     if (res_lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds));
-    FRL_LAUNCH(fk, dim3(128), dim3(256), res_lds, st, (const T*)z, E, K, d, (const int32_t*)(ws + L.amb), hdr, idx, (T*)zq,
+    FRL_LAUNCH(fk, dim3(256), dim3(256), res_lds, st, (const T*)z, E, K, d, (const int32_t*)(ws + L.amb), hdr, idx, (T*)zq,
                (int32_t*)(ws + L.counts_fix));
   } else {
     FRL_LAUNCH((vq_fixup_kernel<T>), dim3(VQ_FIX_WAVES / 4), dim3(256), fix_lds, st, (const T*)z, E, K, d,
                (const int32_t*)(ws + L.amb), hdr, idx, (T*)zq, (int32_t*)(ws + L.counts_fix));
   }
   launch_slab_reduce<int32_t, HistEpi>((const int32_t*)(ws + L.hist), L.grid, K, HistEpi{(const int32_t*)(ws + L.counts_fix), counts}, st);
-  FRL_LAUNCH(vq_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)(ws + L.partial), L.grid * 4, (const VqHeader*)hdr,
+  FRL_LAUNCH(vq_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)(ws + L.partial), L.grid * nw, (const VqHeader*)hdr,
              (const int32_t*)counts, K, N, stats);
   return frl_check_launch("vq_assign");
 }
@@ -770,7 +821,7 @@ static int vq_bwd_chunk(int K, int d) {
 extern "C" {
 
 size_t frl_vq_workspace_bytes(int64_t N, int K, int d) {
-  const VqLayout L = vq_layout(N, K);
+  const VqLayout L = vq_layout(N, K, d);
   const size_t bwd = (size_t)VQ_BWD_WGS * K * d * 4 + (size_t)K * d * 4;
   return L.total > bwd ? L.total : bwd;
 }
