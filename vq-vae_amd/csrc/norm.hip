@@ -7,11 +7,12 @@
 #include "frl_host.hpp"
 #include "frl_reduce.hpp"
 
-// One workgroup per sample.  Thread layout: vpr = C / V channel-vectors per row, rpi = 256 / vpr rows per
+// One workgroup (NTH = 1024 threads: 16 waves keep a sample's 128-256 KB stream in flight) per sample.  Thread layout: vpr = C / V
+// channel-vectors per row, rpi = NTH / vpr rows per
 // iteration; each thread owns a fixed channel vector and strides over rows.  MODE 0: sums of x and x^2;
 // MODE 1 (backward): sums of dyh and dyh * xhat with dyh = dy * relu'(xhat*gamma+beta).
-template <typename T, int V, int MODE>
-__global__ __launch_bounds__(256) void gn_reduce_kernel(const T* __restrict__ X, const T* __restrict__ DY,
+template <typename T, int V, int MODE, int NTH>
+__global__ __launch_bounds__(NTH) void gn_reduce_kernel(const T* __restrict__ X, const T* __restrict__ DY,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         int HW, int C, int G, float eps, int relu,
@@ -21,7 +22,7 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const T* __restrict__ X,
   float* red = reinterpret_cast<float*>(smem);   // [2][rpi][C]
   const int b = blockIdx.x, tid = threadIdx.x;
   const int vpr = C / V;
-  const int rpi = 256 / vpr > 0 ? 256 / vpr : 1;
+  const int rpi = NTH / vpr > 0 ? NTH / vpr : 1;
   const int cg = C / G;
   const T* xb = X + (int64_t)b * HW * C;
   float s0[V], s1[V];
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const T* __restrict__ X,
   }
   __syncthreads();
   // per-channel totals (fixed order over rows)
-  for (int i = tid; i < 2 * C; i += 256) {
+  for (int i = tid; i < 2 * C; i += NTH) {
     const int which = i / C, c = i % C;
     float s = 0.f;
     for (int r = 0; r < rpi; ++r) s += red[(which * rpi + r) * C + c];
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const T* __restrict__ X,
       out_b[b * G + tid] = (float)(1.0 / sqrt(var + (double)eps));
     }
   } else {
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += NTH) {
       out_a[(int64_t)b * C + c] = red[c];              // sum dyh          -> d beta contribution
       out_b[(int64_t)b * C + c] = red[rpi * C + c];    // sum dyh * xhat   -> d gamma contribution
     }
@@ -98,59 +99,94 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const T* __restrict__ X,
   }
 }
 
-// y = act(xhat * gamma + beta)
+// y = act(xhat * gamma + beta).  One workgroup = one row chunk of ONE sample; a thread keeps a fixed channel vector, so the per-channel
+// coefficients (rstd*gamma, beta - mean*rstd*gamma) are formed once and the row loop is load -> V FMAs -> store.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ X, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ mean,
-                                                       const float* __restrict__ rstd, T* __restrict__ Y, int64_t total_vec,
+                                                       const float* __restrict__ rstd, T* __restrict__ Y, int rows_per_wg,
                                                        int HW, int C, int G, int relu) {
   const int vpr = C / V, cg = C / G;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
-    const int c0 = (int)(i % vpr) * V;
-    const int64_t row = i / vpr;
-    const int b = (int)(row / HW);
+  const int rpi = 256 / vpr;                       // rows per iteration (launcher guarantees vpr <= 256)
+  const int b = blockIdx.y, cv = threadIdx.x % vpr, r0 = threadIdx.x / vpr;
+  if (r0 >= rpi) return;
+  const int c0 = cv * V;
+  float a[V], o[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const int c = c0 + e, g = c / cg;
+    a[e] = rstd[b * G + g] * gamma[c];
+    o[e] = fmaf(-mean[b * G + g], a[e], beta[c]);
+  }
+  const int row_lo = blockIdx.x * rows_per_wg;
+  const int row_hi = (row_lo + rows_per_wg) < HW ? (row_lo + rows_per_wg) : HW;
+  const T* xb = X + (int64_t)b * HW * C + c0;
+  T* yb = Y + (int64_t)b * HW * C + c0;
+  for (int r = row_lo + r0; r < row_hi; r += rpi) {
     float xv[V], yv[V];
-    if constexpr (V == 1) xv[0] = to_f32(X[row * C + c0]); else Vec<T>::load(X + row * C + c0, xv);
+    if constexpr (V == 1) xv[0] = to_f32(xb[(int64_t)r * C]); else Vec<T>::load(xb + (int64_t)r * C, xv);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      const int c = c0 + e, g = c / cg;
-      const float a = rstd[b * G + g] * gamma[c];
-      float v = fmaf(xv[e] - mean[b * G + g], a, beta[c]);
+      float v = fmaf(xv[e], a[e], o[e]);
       if (relu) v = v > 0.f ? v : 0.f;
       yv[e] = v;
     }
-    if constexpr (V == 1) Y[row * C + c0] = from_f32<T>(yv[0]); else Vec<T>::store(Y + row * C + c0, yv);
+    if constexpr (V == 1) yb[(int64_t)r * C] = from_f32<T>(yv[0]); else Vec<T>::store(yb + (int64_t)r * C, yv);
   }
 }
 
-// dx = rstd * (dyh * gamma - (S1 + xhat * S2) / n)
+// dx = rstd * (dyh * gamma - (S1 + xhat * S2) / n)  =  A * dyh + E * x + F  with per-(sample, channel) constants
 template <typename T, int V>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ X, const T* __restrict__ DY,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                           const float* __restrict__ grp, T* __restrict__ DX, int64_t total_vec,
+                                                           const float* __restrict__ grp, T* __restrict__ DX, int rows_per_wg,
                                                            int HW, int C, int G, int relu) {
   const int vpr = C / V, cg = C / G;
+  const int rpi = 256 / vpr;
+  const int b = blockIdx.y, cv = threadIdx.x % vpr, r0 = threadIdx.x / vpr;
+  if (r0 >= rpi) return;
+  const int c0 = cv * V;
   const float inv_n = 1.f / ((float)cg * (float)HW);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
-    const int c0 = (int)(i % vpr) * V;
-    const int64_t row = i / vpr;
-    const int b = (int)(row / HW);
+  float A[V], E[V], F[V], ma[V], mo[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const int c = c0 + e, g = c / cg;
+    const float rs = rstd[b * G + g], mu = mean[b * G + g];
+    const float S1 = grp[(b * G + g) * 2], S2 = grp[(b * G + g) * 2 + 1];
+    A[e] = rs * gamma[c];
+    E[e] = -rs * rs * S2 * inv_n;                  // coefficient of x:      -rstd * S2/n * xhat, xhat = (x - mean) * rstd
+    F[e] = -rs * S1 * inv_n - E[e] * mu;
+    ma[e] = A[e];                                  // relu mask: xhat*gamma + beta = x * ma + mo
+    mo[e] = fmaf(-mu, A[e], beta[c]);
+  }
+  const int row_lo = blockIdx.x * rows_per_wg;
+  const int row_hi = (row_lo + rows_per_wg) < HW ? (row_lo + rows_per_wg) : HW;
+  const T* xb = X + (int64_t)b * HW * C + c0;
+  const T* db = DY + (int64_t)b * HW * C + c0;
+  T* ob = DX + (int64_t)b * HW * C + c0;
+  for (int r = row_lo + r0; r < row_hi; r += rpi) {
     float xv[V], dv[V], ov[V];
-    if constexpr (V == 1) { xv[0] = to_f32(X[row * C + c0]); dv[0] = to_f32(DY[row * C + c0]); }
-    else { Vec<T>::load(X + row * C + c0, xv); Vec<T>::load(DY + row * C + c0, dv); }
+    if constexpr (V == 1) { xv[0] = to_f32(xb[(int64_t)r * C]); dv[0] = to_f32(db[(int64_t)r * C]); }
+    else { Vec<T>::load(xb + (int64_t)r * C, xv); Vec<T>::load(db + (int64_t)r * C, dv); }
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      const int c = c0 + e, g = c / cg;
-      const float rs = rstd[b * G + g];
-      const float xh = (xv[e] - mean[b * G + g]) * rs;
       float d = dv[e];
-      if (relu && !(fmaf(xh, gamma[c], beta[c]) > 0.f)) d = 0.f;
-      const float S1 = grp[(b * G + g) * 2], S2 = grp[(b * G + g) * 2 + 1];
-      ov[e] = rs * (d * gamma[c] - (S1 + xh * S2) * inv_n);
+      if (relu && !(fmaf(xv[e], ma[e], mo[e]) > 0.f)) d = 0.f;
+      ov[e] = fmaf(A[e], d, fmaf(E[e], xv[e], F[e]));
     }
-    if constexpr (V == 1) DX[row * C + c0] = from_f32<T>(ov[0]); else Vec<T>::store(DX + row * C + c0, ov);
+    if constexpr (V == 1) ob[(int64_t)r * C] = from_f32<T>(ov[0]); else Vec<T>::store(ob + (int64_t)r * C, ov);
   }
+}
+
+// rows per workgroup of the apply kernels: a multiple of the rows per iteration, sized for >= ~8 workgroups per CU overall
+static int gn_rows_per_wg(int B, int HW, int rpi) {
+  int chunks = (2048 + B - 1) / B;                 // workgroups per sample
+  if (chunks < 1) chunks = 1;
+  int rpw = (HW + chunks - 1) / chunks;
+  rpw = (rpw + rpi - 1) / rpi * rpi;
+  if (rpw < 4 * rpi) rpw = 4 * rpi;                // at least four iterations to amortise the coefficient set-up
+  return rpw;
 }
 
 struct StoreEpi {
@@ -163,14 +199,17 @@ static int gn_fwd_impl(const void* x, const float* gamma, const float* beta, voi
                        int HW, int C, int G, float eps, int relu, hipStream_t st) {
   const int vpr = C / V;
   const int rpi = 256 / vpr > 0 ? 256 / vpr : 1;
-  const size_t lds = (size_t)2 * rpi * C * sizeof(float);
-  FRL_LAUNCH((gn_reduce_kernel<T, V, 0>), dim3(B), dim3(256), lds, st, (const T*)x, (const T*)nullptr, gamma, beta,
-                     (const float*)nullptr, (const float*)nullptr, HW, C, G, eps, 0, mean, rstd, (float*)nullptr);
-  const int64_t tv = (int64_t)B * HW * vpr;
-  int64_t grid = (tv + 255) / 256;
-  if (grid > 4096) grid = 4096;
-  FRL_LAUNCH((gn_apply_kernel<T, V>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)x, gamma, beta,
-                     (const float*)mean, (const float*)rstd, (T*)y, tv, HW, C, G, relu);
+  constexpr int NTH = 1024;
+  const size_t lds = (size_t)2 * (NTH / vpr > 0 ? NTH / vpr : 1) * C * sizeof(float);
+  {
+    auto kern = gn_reduce_kernel<T, V, 0, NTH>;
+    if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FRL_LAUNCH(kern, dim3(B), dim3(NTH), lds, st, (const T*)x, (const T*)nullptr, gamma, beta,
+               (const float*)nullptr, (const float*)nullptr, HW, C, G, eps, 0, mean, rstd, (float*)nullptr);
+  }
+  const int rpw = gn_rows_per_wg(B, HW, rpi);
+  FRL_LAUNCH((gn_apply_kernel<T, V>), dim3((unsigned)((HW + rpw - 1) / rpw), (unsigned)B), dim3(256), 0, st, (const T*)x, gamma, beta,
+                     (const float*)mean, (const float*)rstd, (T*)y, rpw, HW, C, G, relu);
   return frl_check_launch("groupnorm_fwd");
 }
 
@@ -180,17 +219,19 @@ static int gn_bwd_impl(const void* dy, const void* x, const float* gamma, const 
                        float* ws, hipStream_t st) {
   const int vpr = C / V;
   const int rpi = 256 / vpr > 0 ? 256 / vpr : 1;
-  const size_t lds = (size_t)2 * rpi * C * sizeof(float);
+  constexpr int NTH = 1024;
+  const size_t lds = (size_t)2 * (NTH / vpr > 0 ? NTH / vpr : 1) * C * sizeof(float);
   float* sdy = ws;                         // [B][C]
   float* sdyx = ws + (size_t)B * C;        // [B][C]
   float* grp = ws + (size_t)2 * B * C;     // [B][G][2]
-  FRL_LAUNCH((gn_reduce_kernel<T, V, 1>), dim3(B), dim3(256), lds, st, (const T*)x, (const T*)dy, gamma, beta, mean,
-                     rstd, HW, C, G, 0.f, relu, sdy, sdyx, grp);
-  const int64_t tv = (int64_t)B * HW * vpr;
-  int64_t grid = (tv + 255) / 256;
-  if (grid > 4096) grid = 4096;
-  FRL_LAUNCH((gn_bwd_apply_kernel<T, V>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)x, (const T*)dy, gamma,
-                     beta, mean, rstd, (const float*)grp, (T*)dx, tv, HW, C, G, relu);
+  {
+    auto kern = gn_reduce_kernel<T, V, 1, NTH>;
+    if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FRL_LAUNCH(kern, dim3(B), dim3(NTH), lds, st, (const T*)x, (const T*)dy, gamma, beta, mean, rstd, HW, C, G, 0.f, relu, sdy, sdyx, grp);
+  }
+  const int rpw = gn_rows_per_wg(B, HW, rpi);
+  FRL_LAUNCH((gn_bwd_apply_kernel<T, V>), dim3((unsigned)((HW + rpw - 1) / rpw), (unsigned)B), dim3(256), 0, st, (const T*)x, (const T*)dy,
+                     gamma, beta, mean, rstd, (const float*)grp, (T*)dx, rpw, HW, C, G, relu);
   launch_slab_reduce<float, StoreEpi>((const float*)sdy, B, C, StoreEpi{dbeta}, st);
   launch_slab_reduce<float, StoreEpi>((const float*)sdyx, B, C, StoreEpi{dgamma}, st);
   return frl_check_launch("groupnorm_bwd");
