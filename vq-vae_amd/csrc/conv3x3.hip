@@ -11,6 +11,7 @@
 // Roofline: MFMA (147 456 FLOP/px at 128->64 vs 384 B/px bf16 = 384 FLOP/B, above the 312 FLOP/B balance point).
 #include "frl_common.hpp"
 #include "frl_host.hpp"
+#include <type_traits>
 #include "frl_reduce.hpp"
 
 #define C3_TH 8
@@ -99,7 +100,60 @@ __global__ void c3_pack_kernel(typename DT<T>::frag_t* __restrict__ dst, const f
   }
 }
 
-#define C3F_TH 16      // forward / bwd_data tile: 16 x 16 pixels, 8 waves x 2 rows (2 waves per SIMD hide the staging latency)
+#define C3F_TH 16      // forward / bwd_data tile: 16 x 16 pixels, 8 waves x 2 rows (2 waves per SIMD)
+
+// Halo staging split in two so that the global loads of the NEXT stage fly behind the MFMA taps of the current one:
+//   c3_halo_fetch : issues every 16-byte load of the (TH+2) x 18 x CK halo into registers (zero padding resolved by predication)
+//   c3_halo_commit: applies the optional activation-derivative mask and writes the registers into the LDS halo
+template <typename T, int CK, int NTHR>
+struct C3Halo {
+  static constexpr int V = DT<T>::VEC;
+  static constexpr int VPC = CK / V;
+  static constexpr int TOTAL = (C3F_TH + 2) * C3_WP * VPC;
+  static constexpr int ITEMS = (TOTAL + NTHR - 1) / NTHR;
+  typedef typename std::conditional<sizeof(T) == 2, bf16x8, f32x4>::type vec_t;
+  vec_t x[ITEMS], m[ITEMS];
+};
+
+template <typename T, int CK, int NTHR>
+__device__ __forceinline__ void c3_halo_fetch(C3Halo<T, CK, NTHR>& h, const T* __restrict__ X, const T* __restrict__ M, int b, int y0, int x0,
+                                              int H, int W, int C, int ck, int tid) {
+  typedef C3Halo<T, CK, NTHR> HT;
+  typedef typename HT::vec_t vec_t;
+#pragma unroll
+  for (int u = 0; u < HT::ITEMS; ++u) {
+    const int i = tid + u * NTHR;
+    const int px = i / HT::VPC, c0 = (i % HT::VPC) * HT::V;
+    const int hy = px / C3_WP, hx = px % C3_WP;
+    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+    const bool ok = i < HT::TOTAL && gy >= 0 && gy < H && gx >= 0 && gx < W && ck + c0 < C;
+    const int64_t off = ok ? ((((int64_t)b * H + gy) * W + gx) * C + ck + c0) : 0;
+    vec_t v = *reinterpret_cast<const vec_t*>(X + off);
+    if (!ok) v = vec_t{};
+    h.x[u] = v;
+    if (M != nullptr) h.m[u] = *reinterpret_cast<const vec_t*>(M + off);
+  }
+}
+
+template <typename T, int CK, int NTHR>
+__device__ __forceinline__ void c3_halo_commit(const C3Halo<T, CK, NTHR>& h, T* __restrict__ halo, int pitch, bool has_mask, int mask_act,
+                                               int tid) {
+  typedef C3Halo<T, CK, NTHR> HT;
+  typedef typename HT::vec_t vec_t;
+#pragma unroll
+  for (int u = 0; u < HT::ITEMS; ++u) {
+    const int i = tid + u * NTHR;
+    if (i >= HT::TOTAL) continue;
+    const int px = i / HT::VPC, c0 = (i % HT::VPC) * HT::V;
+    vec_t v = h.x[u];
+    if (has_mask) {
+#pragma unroll
+      for (int e = 0; e < HT::V; ++e) v[e] = from_f32<T>(to_f32(v[e]) * act_bwd_from_y(to_f32(h.m[u][e]), mask_act));
+    }
+    *reinterpret_cast<vec_t*>(halo + px * pitch + c0) = v;
+  }
+}
+
 template <typename T, int NF>
 __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, const T* __restrict__ Xmask, int mask_act,
                                                       const typename DT<T>::frag_t* __restrict__ Wpk,
@@ -115,24 +169,59 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, kc = lane >> 4;
   const int tiles_x = (W + C3_TW - 1) / C3_TW, tiles_y = (H + C3F_TH - 1) / C3F_TH;
-  const int bid = (int)xcd_remap(blockIdx.x, gridDim.x);     // the tiles of one image share an XCD (halo rows hit its L2)
-  const int b = bid / (tiles_x * tiles_y), tyx = bid % (tiles_x * tiles_y);
-  const int y0 = (tyx / tiles_x) * C3F_TH, x0 = (tyx % tiles_x) * C3_TW;
+  const int ntiles = B * tiles_x * tiles_y;
   const int MB = (Cout + 15) >> 4, qo = 4 * MB;
-
-  for (int oc0 = 0; oc0 < MB; oc0 += 4) {
+  const int nck = (Cin + CK - 1) / CK, noc = (MB + 3) / 4;
+  const bool fast = (Cin % DT<T>::VEC) == 0;                    // 16-byte channel vectors: register-prefetched staging
+  const bool has_mask = Xmask != nullptr;
+  // Persistent workgroups over a flat sequence of stages (tile, out-chunk, in-chunk); tile order is XCD-aware (the tiles of one
+  // image share an XCD, halo rows hit its L2).  With a single weight block (64 -> 64) the 72 KB image is loaded once per workgroup.
+  const int bid0 = (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int my_tiles = bid0 < ntiles ? (ntiles - bid0 + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int per_tile = noc * nck, nstage = my_tiles * per_tile;
+  int wl_block = -1;                                             // packed-weight block currently resident in LDS
+  C3Halo<T, CK, 512> hreg;
+  auto stage_geom = [&](int st, int& b, int& y0, int& x0, int& oc_i, int& ck_i) {
+    const int ti = st / per_tile, r = st % per_tile;
+    const int bid = bid0 + ti * (int)gridDim.x;
+    b = bid / (tiles_x * tiles_y);
+    const int tyx = bid % (tiles_x * tiles_y);
+    y0 = (tyx / tiles_x) * C3F_TH; x0 = (tyx % tiles_x) * C3_TW;
+    oc_i = r / nck; ck_i = r % nck;
+  };
+  if (fast && nstage > 0) {
+    int b, y0, x0, oc_i, ck_i;
+    stage_geom(0, b, y0, x0, oc_i, ck_i);
+    c3_halo_fetch<T, CK, 512>(hreg, X, Xmask, b, y0, x0, H, W, Cin, ck_i * CK, tid);
+  }
+  f32x4 acc[2][4];
+  for (int st = 0; st < nstage; ++st) {
+    int b, y0, x0, oc_i, ck_i;
+    stage_geom(st, b, y0, x0, oc_i, ck_i);
+    const int oc0 = oc_i * 4, ck = ck_i * CK;
     const int nmb = (MB - oc0) < 4 ? (MB - oc0) : 4;
-    f32x4 acc[2][4];
+    if (ck_i == 0) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int m = 0; m < 4; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int ck = 0; ck < Cin; ck += CK) {
-      __syncthreads();
-      stage_halo<T, C3F_TH, 512>(halo, pitch, X, Xmask, mask_act, b, y0, x0, H, W, Cin, ck, CK, tid);
+        for (int m = 0; m < 4; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    {
+      __syncthreads();                                           // the previous stage is done with halo / wl
+      if (fast) c3_halo_commit<T, CK, 512>(hreg, halo, pitch, has_mask, mask_act, tid);
+      else stage_halo<T, C3F_TH, 512>(halo, pitch, X, Xmask, mask_act, b, y0, x0, H, W, Cin, ck, CK, tid);
       // weights of this (out-chunk, in-chunk): wl[((tap*4 + m)*NF + s)*64 + lane], copied from the packed image
-      copy_frags_lds<T>(wl, Wpk + (size_t)((oc0 / 4) * ((Cin + CK - 1) / CK) + ck / CK) * (9 * 4 * NF * 64), 9 * 4 * NF * 64, tid, 512);
+      const int blk = oc_i * nck + ck_i;
+      if (blk != wl_block) {
+        copy_frags_lds<T>(wl, Wpk + (size_t)blk * (9 * 4 * NF * 64), 9 * 4 * NF * 64, tid, 512);
+        wl_block = blk;
+      }
       __syncthreads();
+      if (fast && st + 1 < nstage) {                             // next stage's halo loads fly behind this stage's MFMA taps
+        int b2, y2, x2, oc2, ck2;
+        stage_geom(st + 1, b2, y2, x2, oc2, ck2);
+        c3_halo_fetch<T, CK, 512>(hreg, X, Xmask, b2, y2, x2, H, W, Cin, ck2 * CK, tid);
+      }
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap % 3;
@@ -159,6 +248,7 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
         }
       }
     }
+    if (ck_i != nck - 1) continue;
     // epilogue
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -364,7 +454,8 @@ static int launch_c3(const void* x, const void* xm, int mask_act, const float* w
   auto kern = conv3x3_kernel<T, NF>;
   FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int tiles = B * ((H + C3F_TH - 1) / C3F_TH) * ((W + C3_TW - 1) / C3_TW);
-  FRL_LAUNCH(kern, dim3(tiles), dim3(512), lds, st, (const T*)x, (const T*)xm, mask_act, (const frag_t*)ws, bias, (T*)y, B,
+  const int grid = tiles < 256 ? tiles : 256;                  // LDS allows one workgroup per CU: persistent over the tiles
+  FRL_LAUNCH(kern, dim3(grid), dim3(512), lds, st, (const T*)x, (const T*)xm, mask_act, (const frag_t*)ws, bias, (T*)y, B,
                      H, W, Cin, Cout, act);
   return frl_check_launch("conv3x3");
 }
