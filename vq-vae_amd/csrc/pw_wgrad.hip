@@ -10,6 +10,7 @@
 #include "frl_common.hpp"
 #include "frl_host.hpp"
 #include "frl_reduce.hpp"
+#include <type_traits>
 
 #define WG_KP 64
 
@@ -19,65 +20,113 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(
     float* __restrict__ slab, int64_t P, int Cout, int Cin, int64_t rows_per_wg, int HW, int Tn, int toff,
     int use_tr) {
   typedef typename DT<T>::frag_t frag_t;
+  typedef typename std::conditional<sizeof(T) == 2, bf16x8, f32x4>::type vec_t;
   constexpr int FE = DT<T>::FE;
   constexpr int VEC = DT<T>::VEC;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int CoP = OBW * 4 * 16, CiP = IB * 16;
-  const int pitchA = CoP + 8, pitchB = CiP + 8;      // elements; keeps 16-B row alignment, skews banks
+  constexpr int CoP = OBW * 4 * 16, CiP = IB * 16;
+  constexpr int pitchA = CoP + 8, pitchB = CiP + 8;      // elements; keeps 16-B row alignment, skews banks
+  constexpr int VPRA = CoP / VEC, VPRB = CiP / VEC;       // 16-byte vectors per staged row
+  constexpr int NA = (WG_KP * VPRA + 255) / 256, NB = (WG_KP * VPRB + 255) / 256;   // vectors per thread and tile
   T* ldsA = reinterpret_cast<T*>(smem);
   T* ldsB = ldsA + WG_KP * pitchA;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, kc = lane >> 4;
 
-  f32x4 acc[OBW][IB];
+  f32x4 acc[OBW][IB], accb[OBW];
 #pragma unroll
-  for (int o = 0; o < OBW; ++o)
+  for (int o = 0; o < OBW; ++o) {
+    accb[o] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < IB; ++i) acc[o][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
+  }
 
   const int64_t p_begin = (int64_t)blockIdx.x * rows_per_wg;
   int64_t p_end = p_begin + rows_per_wg;
   if (p_end > P) p_end = P;
   const bool fastA = (Cout % VEC) == 0, fastB = (Cin % VEC) == 0;
+  const bool fast = fastA && fastB;                          // 16-byte channel vectors: tiles are prefetched into registers
   const int64_t shift = (int64_t)toff * HW;
+
+  // register images of the next tile (fast path): raw dY / mask / X vectors, fetched behind the MFMAs of the current tile
+  vec_t ra[NA], rm[NA], rb[NB];
+  auto fetch = [&](int64_t p0) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int i = tid + u * 256;
+      const int row = i / VPRA, c0 = (i % VPRA) * VEC;
+      const int64_t p = p0 + row;
+      const bool ok = i < WG_KP * VPRA && p < p_end && c0 < Cout;
+      const int64_t off = ok ? p * (int64_t)Cout + c0 : 0;
+      vec_t v = *reinterpret_cast<const vec_t*>(dY + off);
+      if (!ok) v = vec_t{};
+      ra[u] = v;
+      if (Ymask != nullptr) rm[u] = *reinterpret_cast<const vec_t*>(Ymask + off);
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int i = tid + u * 256;
+      const int row = i / VPRB, c0 = (i % VPRB) * VEC;
+      const int64_t p = p0 + row;
+      bool ok = i < WG_KP * VPRB && p < p_end && c0 < Cin;
+      if (ok && Tn > 1) {
+        const int t = (int)((p / HW) % Tn) + toff;
+        ok = (t >= 0 && t < Tn);
+      }
+      const int64_t off = ok ? (p + shift) * (int64_t)Cin + c0 : 0;
+      vec_t v = *reinterpret_cast<const vec_t*>(X + off);
+      if (!ok) v = vec_t{};
+      rb[u] = v;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int i = tid + u * 256;
+      if (i >= WG_KP * VPRA) continue;
+      const int row = i / VPRA, c0 = (i % VPRA) * VEC;
+      vec_t v = ra[u];
+      if (Ymask != nullptr) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = from_f32<T>(to_f32(v[e]) * act_bwd_from_y(to_f32(rm[u][e]), mask_act));
+      }
+      *reinterpret_cast<vec_t*>(ldsA + row * pitchA + c0) = v;
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int i = tid + u * 256;
+      if (i >= WG_KP * VPRB) continue;
+      const int row = i / VPRB, c0 = (i % VPRB) * VEC;
+      *reinterpret_cast<vec_t*>(ldsB + row * pitchB + c0) = rb[u];
+    }
+  };
+  if (fast && p_begin < p_end) fetch(p_begin);
 
   for (int64_t p0 = p_begin; p0 < p_end; p0 += WG_KP) {
     __syncthreads();
-    // ---- stage dY tile (with activation-derivative mask) ----
-    {
-      const int vpr = CoP / VEC;                         // vectors per row
-      for (int i = tid; i < WG_KP * vpr; i += 256) {
-        const int row = i / vpr, c0 = (i % vpr) * VEC;
+    if (fast) {
+      commit();
+    } else {
+      // ---- generic staging (channel counts that are not a multiple of the vector width) ----
+      for (int i = tid; i < WG_KP * VPRA; i += 256) {
+        const int row = i / VPRA, c0 = (i % VPRA) * VEC;
         const int64_t p = p0 + row;
         float v[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) v[e] = 0.f;
         if (p < p_end && c0 < Cout) {
           const T* src = dY + p * (int64_t)Cout + c0;
-          if (fastA) {
-            Vec<T>::load(src, v);
-            if (Ymask != nullptr) {
-              float m[VEC];
-              Vec<T>::load(Ymask + p * (int64_t)Cout + c0, m);
 #pragma unroll
-              for (int e = 0; e < VEC; ++e) v[e] *= act_bwd_from_y(m[e], mask_act);
+          for (int e = 0; e < VEC; ++e)
+            if (c0 + e < Cout) {
+              v[e] = to_f32(src[e]);
+              if (Ymask != nullptr) v[e] *= act_bwd_from_y(to_f32(Ymask[p * (int64_t)Cout + c0 + e]), mask_act);
             }
-          } else {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e)
-              if (c0 + e < Cout) {
-                v[e] = to_f32(src[e]);
-                if (Ymask != nullptr) v[e] *= act_bwd_from_y(to_f32(Ymask[p * (int64_t)Cout + c0 + e]), mask_act);
-              }
-          }
         }
         Vec<T>::store(ldsA + row * pitchA + c0, v);
       }
-      // ---- stage X tile (row-shifted, zero outside the valid time range) ----
-      const int vprb = CiP / VEC;
-      for (int i = tid; i < WG_KP * vprb; i += 256) {
-        const int row = i / vprb, c0 = (i % vprb) * VEC;
+      for (int i = tid; i < WG_KP * VPRB; i += 256) {
+        const int row = i / VPRB, c0 = (i % VPRB) * VEC;
         const int64_t p = p0 + row;
         float v[VEC];
 #pragma unroll
@@ -89,25 +138,19 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(
         }
         if (ok) {
           const T* src = X + (p + shift) * (int64_t)Cin + c0;
-          if (fastB) Vec<T>::load(src, v);
-          else {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e)
-              if (c0 + e < Cin) v[e] = to_f32(src[e]);
-          }
+          for (int e = 0; e < VEC; ++e)
+            if (c0 + e < Cin) v[e] = to_f32(src[e]);
         }
         Vec<T>::store(ldsB + row * pitchB + c0, v);
       }
     }
     __syncthreads();
-    // ---- bias gradient: column sums of the staged dY tile ----
-    if (tid < Cout) {
-      float s = 0.f;
-      for (int row = 0; row < WG_KP; ++row) s += to_f32(ldsA[row * pitchA + tid]);
-      bsum += s;
-    }
-    // ---- MFMA over the tile's pixels ----
+    if (fast && p0 + WG_KP < p_end) fetch(p0 + WG_KP);       // next tile's loads fly behind this tile's MFMAs
+    // ---- MFMA over the tile's pixels; the bias gradient (column sums of dY) rides along against a "ones" column ----
     if constexpr (FE == 8) {
+      const bf16x8 ones = (r16 == 0) ? bf16x8{(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f}
+                                     : bf16x8{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
 #pragma unroll
       for (int ks = 0; ks < WG_KP / 32; ++ks) {
         const int pix0 = ks * 32 + 8 * kc;
@@ -145,9 +188,11 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(
           }
 #pragma unroll
           for (int i = 0; i < IB; ++i) acc[o][i] = mfma16(af, bf[i], acc[o][i]);
+          accb[o] = mfma16(af, ones, accb[o]);
         }
       }
     } else {
+      const float ones = (r16 == 0) ? 1.f : 0.f;
 #pragma unroll 4
       for (int ks = 0; ks < WG_KP / 4; ++ks) {
         const int pix = ks * 4 + kc;
@@ -159,6 +204,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(
           const float af = ldsA[pix * pitchA + (wave * OBW + o) * 16 + r16];
 #pragma unroll
           for (int i = 0; i < IB; ++i) acc[o][i] = mfma16(af, bf[i], acc[o][i]);
+          accb[o] = mfma16(af, ones, accb[o]);
         }
       }
     }
@@ -174,7 +220,15 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(
         const int oc = (wave * OBW + o) * 16 + kc * 4 + r, ic = i * 16 + r16;
         if (oc < Cout && ic < Cin) my[(int64_t)oc * Cin + ic] = acc[o][i][r];
       }
-  if (tid < Cout) my[(int64_t)Cout * Cin + tid] = bsum;
+  if (r16 == 0) {                                            // column 0 of the "ones" product holds the row sums
+#pragma unroll
+    for (int o = 0; o < OBW; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int oc = (wave * OBW + o) * 16 + kc * 4 + r;
+        if (oc < Cout) my[(int64_t)Cout * Cin + oc] = accb[o][r];
+      }
+  }
 }
 
 // Epilogue of the fixed-order slab reduction (frl_reduce.hpp).  dw strides let the caller scatter a tap slice of a
