@@ -154,6 +154,9 @@ __device__ __forceinline__ void c3_halo_commit(const C3Halo<T, CK, NTHR>& h, T* 
   }
 }
 
+#ifdef C3_STAMPS
+__device__ unsigned long long* c3_dbg;       // diagnostic build only (tools/diag/c3_stamps.hip)
+#endif
 template <typename T, int NF>
 __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, const T* __restrict__ Xmask, int mask_act,
                                                       const typename DT<T>::frag_t* __restrict__ Wpk,
@@ -181,6 +184,14 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
   const int per_tile = noc * nck, nstage = my_tiles * per_tile;
   int wl_block = -1;                                             // packed-weight block currently resident in LDS
   C3Halo<T, CK, 512> hreg;
+#ifdef C3_STAMPS
+  __shared__ unsigned long long c3_ts[8][8];
+  if (tid < 64) (&c3_ts[0][0])[tid] = 0ull;
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#define C3_ST(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); if (lane == 0) c3_ts[wave][i] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define C3_ST(i) do { } while (0)
+#endif
   auto stage_geom = [&](int st, int& b, int& y0, int& x0, int& oc_i, int& ck_i) {
     const int ti = st / per_tile, r = st % per_tile;
     const int bid = bid0 + ti * (int)gridDim.x;
@@ -207,7 +218,9 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
         for (int m = 0; m < 4; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     {
+      C3_ST(0);                                                  // (epilogue + loop overhead of the previous stage)
       __syncthreads();                                           // the previous stage is done with halo / wl
+      C3_ST(1);
       if (fast) c3_halo_commit<T, CK, 512>(hreg, halo, pitch, has_mask, mask_act, tid);
       else stage_halo<T, C3F_TH, 512>(halo, pitch, X, Xmask, mask_act, b, y0, x0, H, W, Cin, ck, CK, tid);
       // weights of this (out-chunk, in-chunk): wl[((tap*4 + m)*NF + s)*64 + lane], copied from the packed image
@@ -216,7 +229,9 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
         copy_frags_lds<T>(wl, Wpk + (size_t)blk * (9 * 4 * NF * 64), 9 * 4 * NF * 64, tid, 512);
         wl_block = blk;
       }
+      C3_ST(2);                                                  // halo commit (waits for the prefetched loads) + weight copy
       __syncthreads();
+      C3_ST(3);
       if (fast && st + 1 < nstage) {                             // next stage's halo loads fly behind this stage's MFMA taps
         int b2, y2, x2, oc2, ck2;
         stage_geom(st + 1, b2, y2, x2, oc2, ck2);
@@ -248,6 +263,7 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
         }
       }
     }
+    C3_ST(4);                                                    // prefetch issue + 9 MFMA taps
     if (ck_i != nck - 1) continue;
     // epilogue
 #pragma unroll
@@ -277,6 +293,10 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
       }
     }
   }
+#ifdef C3_STAMPS
+  __syncthreads();
+  if (tid < 64) c3_dbg[(size_t)blockIdx.x * 64 + tid] = (&c3_ts[0][0])[tid];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
