@@ -169,8 +169,10 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* halo = reinterpret_cast<T*>(smem);
   frag_t* wl = reinterpret_cast<frag_t*>(smem + (size_t)(C3F_TH + 2) * C3_WP * pitch * sizeof(T));
+  float* bias_l = reinterpret_cast<float*>(wl + 9 * 4 * NF * 64);   // [Cout padded to 16] (zeros without a bias)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, kc = lane >> 4;
+  for (int i = tid; i < ((Cout + 15) & ~15); i += 512) bias_l[i] = (bias != nullptr && i < Cout) ? bias[i] : 0.f;
   const int tiles_x = (W + C3_TW - 1) / C3_TW, tiles_y = (H + C3F_TH - 1) / C3F_TH;
   const int ntiles = B * tiles_x * tiles_y;
   const int MB = (Cout + 15) >> 4, qo = 4 * MB;
@@ -237,40 +239,65 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
         stage_geom(st + 1, b2, y2, x2, oc2, ck2);
         c3_halo_fetch<T, CK, 512>(hreg, X, Xmask, b2, y2, x2, H, W, Cin, ck2 * CK, tid);
       }
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
+      // 9 taps, software-pipelined: the LDS fragments of tap+1 are requested before the MFMAs of tap are issued
+      frag_t bfr[2][2][NF], afr[2][4][NF];
+      auto tap_load = [&](int tap, int buf) {
         const int dy = tap / 3, dx = tap % 3;
-        frag_t bf[2][NF];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const T* hp = halo + ((2 * wave + t + dy) * C3_WP + px + dx) * pitch + q * kc;
 #pragma unroll
           for (int s = 0; s < NF; ++s) {
-            if constexpr (FE == 8) bf[t][s] = *reinterpret_cast<const bf16x8*>(hp + 8 * s);
-            else bf[t][s] = hp[s];
+            if constexpr (FE == 8) bfr[buf][t][s] = *reinterpret_cast<const bf16x8*>(hp + 8 * s);
+            else bfr[buf][t][s] = hp[s];
           }
         }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int s = 0; s < NF; ++s) afr[buf][m][s] = wl[((tap * 4 + m) * NF + s) * 64 + lane];
+      };
+      tap_load(0, 0);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int cur = tap & 1;
+        if (tap + 1 < 9) tap_load(tap + 1, cur ^ 1);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           if (m < nmb) {
 #pragma unroll
-            for (int s = 0; s < NF; ++s) {
-              const frag_t a = wl[((tap * 4 + m) * NF + s) * 64 + lane];
+            for (int s = 0; s < NF; ++s)
 #pragma unroll
-              for (int t = 0; t < 2; ++t) acc[t][m] = mfma16(a, bf[t][s], acc[t][m]);
-            }
+              for (int t = 0; t < 2; ++t) acc[t][m] = mfma16(afr[cur][m][s], bfr[cur][t][s], acc[t][m]);
           }
         }
       }
     }
     C3_ST(4);                                                    // prefetch issue + 9 MFMA taps
     if (ck_i != nck - 1) continue;
-    // epilogue
+    // epilogue: bias comes from the LDS copy made at kernel start; when the lane's 16 output channels are contiguous
+    // (Cout a multiple of 64) they leave as two 16-byte stores per pixel (bf16) instead of four 8-byte ones
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int gy = y0 + 2 * wave + t, gx = x0 + px;
       if (gy >= H || gx >= W) continue;
       T* yp = Y + (((int64_t)b * H + gy) * W + gx) * Cout;
+      if (nmb == 4 && (MB & 3) == 0 && (Cout & 63) == 0) {
+        const int cb = qo * kc + 4 * oc0;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = acc[t][j >> 2][j & 3] + bias_l[cb + j];
+        if (act == FRL_ACT_RELU) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
+        } else if (act == FRL_ACT_SIGMOID) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) v[j] = sigmoid_t<T>(v[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j += DT<T>::VEC) Vec<T>::store(yp + cb + j, v + j);
+        continue;
+      }
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         if (m >= nmb) continue;
@@ -279,7 +306,7 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int c = cb + r;
-          const float bb = (bias != nullptr && c < Cout) ? bias[c] : 0.f;
+          const float bb = c < Cout ? bias_l[c] : 0.f;
           v[r] = act_fwd(acc[t][m][r] + bb, act);
         }
         if ((Cout & 3) == 0 && cb + 3 < Cout) {
@@ -470,7 +497,9 @@ static int launch_c3(const void* x, const void* xm, int mask_act, const float* w
   const size_t nfrag = (size_t)((MBt + 3) / 4) * ((Cin + CK - 1) / CK) * 9 * 4 * NF * 64;
   if (ws == nullptr || ws_bytes < nfrag * sizeof(frag_t)) return frl_fail(-4, "conv3x3: workspace too small for the packed weights");
   FRL_LAUNCH((c3_pack_kernel<T, NF>), dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, (frag_t*)ws, w, so, si, tap_rev, Cin, Cout);
-  const size_t lds = (size_t)(C3F_TH + 2) * C3_WP * (CK + C3<T>::PADE) * sizeof(T) + (size_t)9 * 4 * NF * 64 * sizeof(frag_t);
+  const size_t lds = (size_t)(C3F_TH + 2) * C3_WP * (CK + C3<T>::PADE) * sizeof(T) + (size_t)9 * 4 * NF * 64 * sizeof(frag_t) +
+                     (size_t)((Cout + 15) / 16 * 16) * sizeof(float);
+  if (lds > 160 * 1024) return frl_fail(-3, "conv3x3: LDS budget exceeded");
   auto kern = conv3x3_kernel<T, NF>;
   FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int tiles = B * ((H + C3F_TH - 1) / C3F_TH) * ((W + C3_TW - 1) / C3_TW);

@@ -22,6 +22,8 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(
   const int qo = 4 * MB;
   constexpr int q = NF * FE;
   copy_frags_lds<T>(wl, Wpk, MB * NF * 64, threadIdx.x, 256);
+  float* bias_l = reinterpret_cast<float*>(wl + MB * NF * 64);          // [16 * MB] LDS copy of the bias (zeros without one)
+  for (int i = threadIdx.x; i < 16 * MB; i += 256) bias_l[i] = (bias != nullptr && i < Cout) ? bias[i] : 0.f;
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -78,9 +80,13 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(
           const int cb = qo * kc + 4 * c0;
           float v[16];
 #pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const float b = bias != nullptr ? bias[cb + j] : 0.f;
-            v[j] = act_fwd(acc[t][j >> 2][j & 3] + b, act);
+          for (int j = 0; j < 16; ++j) v[j] = acc[t][j >> 2][j & 3] + bias_l[cb + j];
+          if (act == FRL_ACT_RELU) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
+          } else if (act == FRL_ACT_SIGMOID) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = sigmoid_t<T>(v[j]);
           }
 #pragma unroll
           for (int j = 0; j < 16; j += DT<T>::VEC) Vec<T>::store(yp + cb + j, v + j);
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int c = cb + r;
-            float b = (bias != nullptr && c < Cout) ? bias[c] : 0.f;
+            const float b = c < Cout ? bias_l[c] : 0.f;
             v[r] = act_fwd(acc[t][m][r] + b, act);
           }
           if (vec4_out && cb + 3 < Cout) {
@@ -121,9 +127,10 @@ static int launch_pw(const void* x, const void* xmask, int mask_act, const float
   typedef typename DT<T>::frag_t frag_t;
   constexpr int NT = 1;
   const int MB = (Cout + 15) / 16;
-  const size_t lds = (size_t)MB * NF * 64 * sizeof(frag_t);
+  const size_t wbytes = (size_t)MB * NF * 64 * sizeof(frag_t);
+  const size_t lds = wbytes + (size_t)16 * MB * sizeof(float);
   if (lds > 160 * 1024) return frl_fail(-3, "pw_conv: weights exceed LDS (Cin*Cout too large)");
-  if (ws == nullptr || ws_bytes < lds) return frl_fail(-4, "pw_conv: workspace too small for the packed weights");
+  if (ws == nullptr || ws_bytes < wbytes) return frl_fail(-4, "pw_conv: workspace too small for the packed weights");
   FRL_LAUNCH((pack_weights_kernel<T, NF>), dim3((MB * NF * 64 + 255) / 256), dim3(256), 0, st, (frag_t*)ws, w, Cout, Cin, MB, so, si);
   auto kern = pw_conv_kernel<T, NF, NT>;
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
