@@ -1,5 +1,5 @@
 // Fixed-order parallel reduction of per-workgroup slabs:  v[i] = sum_k slab[k * n + i],  epi(i, v[i]).
-// 256 threads = 32 columns x 8 slab groups; each thread walks its group's slabs 4 at a time (independent loads in
+// 256 threads = 32 columns x 8 slab groups; each thread walks its group's slabs 8 at a time (independent loads in
 // flight), the 8 groups are combined through LDS in a fixed order, so results are bit-reproducible run to run.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -11,17 +11,22 @@ __global__ __launch_bounds__(256) void slab_reduce_t(const V* __restrict__ slab,
   __shared__ V red[8][33];
   const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int64_t i = (int64_t)blockIdx.x * 32 + col;
-  V s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  V s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
   if (i < n) {
     int k = grp;
-    for (; k + 24 < nslab; k += 32) {
+    for (; k + 56 < nslab; k += 64) {            // eight independent loads in flight per thread
       s0 += slab[(int64_t)k * n + i];
       s1 += slab[(int64_t)(k + 8) * n + i];
       s2 += slab[(int64_t)(k + 16) * n + i];
       s3 += slab[(int64_t)(k + 24) * n + i];
+      s4 += slab[(int64_t)(k + 32) * n + i];
+      s5 += slab[(int64_t)(k + 40) * n + i];
+      s6 += slab[(int64_t)(k + 48) * n + i];
+      s7 += slab[(int64_t)(k + 56) * n + i];
     }
     for (; k < nslab; k += 8) s0 += slab[(int64_t)k * n + i];
   }
+  s0 += s4; s1 += s5; s2 += s6; s3 += s7;
   red[grp][col] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (grp == 0 && i < n) {

@@ -568,8 +568,6 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd2_kernel(const bf16* __rest
     frag8 dyo[TH_T];
 #pragma unroll
     for (int t = 0; t < TH_T; ++t) x[t] = th_load(X + off + 16 * kc + t * tstride);
-#pragma unroll
-    for (int t = 0; t < TH_T; ++t) dyo[t] = *reinterpret_cast<const frag8*>(DY + off + co + t * tstride);
     frag8 xo[TH_T];
     f32x4 xh[TH_T][2];
     float mean, rstd;
@@ -594,6 +592,10 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd2_kernel(const bf16* __rest
 #pragma unroll
       for (int t = 0; t < TH_T; ++t) xo[t] = h ? x[t].f[1] : x[t].f[0];
     }
+    // dy is requested only now (its registers would otherwise sit next to x, the conv accumulators and the hoisted weight
+    // fragments): the statistics / n[t] pass below covers most of the latency
+#pragma unroll
+    for (int t = 0; t < TH_T; ++t) dyo[t] = *reinterpret_cast<const frag8*>(DY + off + co + t * tstride);
     if (!cur_valid) {                                              // clamped duplicate pixel: contributes nothing
 #pragma unroll
       for (int t = 0; t < TH_T; ++t) dyo[t] = frag8{};
