@@ -354,7 +354,10 @@ __global__ __launch_bounds__(64 * NWV) void conv3x3_wgrad_kernel(const T* __rest
   const int64_t slab_n = (int64_t)OCT * Cin * 9 + OCT;
   float* my = slab + (int64_t)blockIdx.x * slab_n;
   const bool fastA = (Cout % V) == 0;
-  float bsum = 0.f;
+  // bias gradient = column sums of the staged dY tile: one extra MFMA per fragment against a "ones" column (wave group ib == 0)
+  f32x4 accb[OBW];
+#pragma unroll
+  for (int o = 0; o < OBW; ++o) accb[o] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int ck = 0; ck < Cin; ck += CK) {
     f32x4 acc[9][OBW];
@@ -396,12 +399,9 @@ __global__ __launch_bounds__(64 * NWV) void conv3x3_wgrad_kernel(const T* __rest
       }
       stage_halo<T, WTH, NTHR>(halo, pitchB, X, (const T*)nullptr, 0, b, y0, x0, H, W, Cin, ck, CK, tid);
       __syncthreads();
-      if (ck == 0 && tid < OCT) {
-        float s = 0.f;
-        for (int p = 0; p < WTH * C3_TW; ++p) s += to_f32(ldsA[p * pitchA + tid]);
-        bsum += s;
-      }
       if constexpr (FE == 8) {
+        const bf16x8 ones = (r16 == 0) ? bf16x8{(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f}
+                                       : bf16x8{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
 #pragma unroll 1
         for (int ks = 0; ks < WTH / 2; ++ks) {
           const int row = 2 * ks + (kc >> 1), col = 8 * (kc & 1);
@@ -419,6 +419,10 @@ __global__ __launch_bounds__(64 * NWV) void conv3x3_wgrad_kernel(const T* __rest
 #pragma unroll
               for (int j = 0; j < 8; ++j) af[o][j] = ldsA[(pb + j) * pitchA + ch0 + r16];
             }
+          }
+          if (ck == 0 && ib == 0) {
+#pragma unroll
+            for (int o = 0; o < OBW; ++o) accb[o] = mfma16(af[o], ones, accb[o]);
           }
 #pragma unroll
           for (int tap = 0; tap < 9; ++tap) {
@@ -439,6 +443,7 @@ __global__ __launch_bounds__(64 * NWV) void conv3x3_wgrad_kernel(const T* __rest
           }
         }
       } else {
+        const float ones = (r16 == 0) ? 1.f : 0.f;
 #pragma unroll 2
         for (int ks = 0; ks < WTH * C3_TW / 4; ++ks) {
           const int pix = 4 * ks + kc;
@@ -446,6 +451,10 @@ __global__ __launch_bounds__(64 * NWV) void conv3x3_wgrad_kernel(const T* __rest
           float af[OBW];
 #pragma unroll
           for (int o = 0; o < OBW; ++o) af[o] = ldsA[pix * pitchA + (og * OBW + o) * 16 + r16];
+          if (ck == 0 && ib == 0) {
+#pragma unroll
+            for (int o = 0; o < OBW; ++o) accb[o] = mfma16(af[o], ones, accb[o]);
+          }
 #pragma unroll
           for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;
@@ -456,7 +465,8 @@ __global__ __launch_bounds__(64 * NWV) void conv3x3_wgrad_kernel(const T* __rest
         }
       }
     }
-    // slab part for this input-channel chunk: my[(ocl * Cin + ic) * 9 + tap]
+    // slab part for this input-channel chunk, tap-major so that the 16 lanes of a row write 64 contiguous bytes:
+    // my[(tap * OCT + ocl) * Cin + ic]  (the reduction epilogue restores the [oc][ic][tap] order of the weight tensor)
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -464,10 +474,15 @@ __global__ __launch_bounds__(64 * NWV) void conv3x3_wgrad_kernel(const T* __rest
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ocl = (og * OBW + o) * 16 + kc * 4 + r, ic = ck + ib * 16 + r16;
-          if (ic < Cin) my[((int64_t)ocl * Cin + ic) * 9 + tap] = acc[tap][o][r];
+          if (ic < Cin) my[((int64_t)tap * OCT + ocl) * Cin + ic] = acc[tap][o][r];
         }
   }
-  if (tid < OCT) my[(int64_t)OCT * Cin * 9 + tid] = bsum;
+  if (ib == 0 && r16 == 0) {                                   // column 0 of the "ones" product holds the row sums
+#pragma unroll
+    for (int o = 0; o < OBW; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) my[(int64_t)OCT * Cin * 9 + (og * OBW + o) * 16 + kc * 4 + r] = accb[o][r];
+  }
 }
 
 // epilogue of the slab reduction: out[oc][j] = sum_wg slab[wg][ocl][j]; rows beyond Cout are dropped
@@ -475,8 +490,10 @@ struct C3Epi {
   int OCT, Cin9, oc_base, Cout; float* dW; float* dB;
   __device__ void operator()(int64_t i, float s) const {
     if (i < (int64_t)OCT * Cin9) {
-      const int ocl = (int)(i / Cin9);
-      if (oc_base + ocl < Cout) dW[(int64_t)(oc_base + ocl) * Cin9 + (i % Cin9)] = s;
+      const int Cin = Cin9 / 9;
+      const int tap = (int)(i / ((int64_t)OCT * Cin)), rem = (int)(i % ((int64_t)OCT * Cin));
+      const int ocl = rem / Cin, ic = rem % Cin;
+      if (oc_base + ocl < Cout) dW[(int64_t)(oc_base + ocl) * Cin9 + ic * 9 + tap] = s;
     } else if (dB != nullptr) {
       const int ocl = (int)(i - (int64_t)OCT * Cin9);
       if (oc_base + ocl < Cout) dB[oc_base + ocl] = s;
