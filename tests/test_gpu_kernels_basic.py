@@ -44,7 +44,8 @@ def test_conv1x1_fwd(dtype, tol, P, cin, cout, act):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-2)])
-@pytest.mark.parametrize("P,cin,cout", [(1024, 64, 128), (1000, 128, 64), (37, 64, 12), (256, 12, 128), (2048, 64, 256)])
+@pytest.mark.parametrize("P,cin,cout", [(1024, 64, 128), (1000, 128, 64), (37, 64, 12), (256, 12, 128), (2048, 64, 256),
+                                        (1536, 64, 512)])   # 512 outputs: mix_head_B at d = 128 (BASELINE configs[3])
 @pytest.mark.parametrize("act", [0, 1])
 def test_conv1x1_bwd(dtype, tol, P, cin, cout, act):
     from frl_hip import ops
@@ -89,7 +90,9 @@ def _vq_case(N, K, d, dtype, seed, ties=False):
                                         (2048, 1024, 64, False), (2048, 640, 128, False), (777, 100, 12, True),
                                         (64, 16, 4, False),
                                         # >= 65536 rows with d <= 64: 16-wave workgroups (one codebook copy per CU), chunks up to 1024 codes
-                                        (65536 + 123, 512, 64, True), (66000, 1024, 64, False), (65600, 1100, 64, False), (65536, 256, 32, True)])
+                                        (65536 + 123, 512, 64, True), (66000, 1024, 64, False), (65600, 1100, 64, False), (65536, 256, 32, True),
+                                        # BASELINE configs[3] codebook (K = 8192, d = 128: MFMA-bound, 32 LDS chunks) at a reduced row count
+                                        (4096, 8192, 128, False)])
 def test_vq_assign_bit_exact(dtype, N, K, d, ties):
     from frl_hip import ops
     dev = _dev()

@@ -239,3 +239,39 @@ def test_ema_quantizer_updates_codebook():
     assert (m.quant.codebook.detach().cpu().double() - cb).abs().max() <= 1e-5 * max(1.0, cb.abs().max().item())
     out["loss"].backward()
     assert m.quant.codebook.grad is None
+
+
+@pytest.mark.parametrize("name,kw,tile_shape", [
+    # BASELINE configs[3]: large codebook K = 8192, d = 128 (encoder channels [128, 128])
+    ("cfg4", dict(codebook_size=8192, emb_dim=128), (2, 5, 32, 32, 64)),
+    # BASELINE configs[4]: type + phase dual codebook, time = 10, 64 x 64 tiles, K = 1024 each
+    ("cfg5", dict(codebook_size=1024, emb_dim=64, phase_codebook_size=1024), (1, 10, 64, 64, 64)),
+])
+def test_other_baseline_configs_run_and_indices_are_exact(name, kw, tile_shape):
+    """The remaining BASELINE.json configurations as parity cases: one bf16 train step runs, every output is finite and the
+    (type and phase) code indices are the exact float64 arg-min of the latents the encoder produced."""
+    from frl_hip.models import VQVAE
+    from frl_hip.training.trainer import VQVAETrainer
+    torch.manual_seed(0)
+    m = VQVAE(in_features=64, beta=0.25, type_encoder_dropout=0.0, phase_tcn_dropout=0.0, compute_dtype=torch.bfloat16, **kw).to(DEV)
+    with torch.no_grad():
+        m.quant.codebook.copy_(torch.randn(m.quant.codebook.shape, generator=torch.Generator().manual_seed(7)))
+        if hasattr(m, "quant_phase"):
+            m.quant_phase.codebook.copy_(torch.randn(m.quant_phase.codebook.shape, generator=torch.Generator().manual_seed(8)) * 0.5)
+    tile = torch.randn(*tile_shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+    out = m.forward_tiles(tile)
+    assert torch.isfinite(out["loss"]).item()
+    d = m.quant.emb_dim
+    z = out["z_type"].detach().float().cpu().reshape(-1, d)
+    e = m.quant.codebook.detach().cpu().to(torch.bfloat16).float()
+    assert np.array_equal(out["idx"].cpu().numpy().astype(np.int64), O.vq_argmin_np(z.numpy(), e.numpy()))
+    if "idx_phase" in out:
+        zp = out["z_phase"].detach().float().cpu().reshape(-1, m.z_phase_dim)
+        ep = m.quant_phase.codebook.detach().cpu().to(torch.bfloat16).float()
+        assert np.array_equal(out["idx_phase"].cpu().numpy().astype(np.int64), O.vq_argmin_np(zp.numpy(), ep.numpy()))
+    tr = VQVAETrainer(m, lr=1e-4, total_steps=10)
+    res = tr.step(tile)
+    assert torch.isfinite(res["loss"]).item() and torch.isfinite(res["grad_norm"]).all().item()
+    assert tr.opt.applied_and_skipped == (1, 0)
+    for n, p in m.named_parameters():
+        assert torch.isfinite(p).all().item(), n

@@ -147,18 +147,20 @@ static int launch_pw(const void* x, const void* xmask, int mask_act, const float
 int frl_pw_dispatch(const void* x, const void* xmask, int mask_act, const float* w, int64_t so, int64_t si,
                     const float* bias, void* y, int64_t P, int Cin, int Cout, int act, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
   if (P <= 0) return 0;
-  if (Cin < 1 || Cout < 1 || Cin > 256 || Cout > 1024) return frl_fail(-2, "pw_conv: unsupported channel count");
+  if (Cin < 1 || Cout < 1 || Cin > 512 || Cout > 1024) return frl_fail(-2, "pw_conv: unsupported channel count (Cin <= 512, Cout <= 1024)");
   if (dtype == FRL_F32) {
     if (Cin <= 16) return launch_pw<float, 4>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
     if (Cin <= 32) return launch_pw<float, 8>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
     if (Cin <= 64) return launch_pw<float, 16>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
     if (Cin <= 128) return launch_pw<float, 32>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
-    return launch_pw<float, 64>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
+    if (Cin <= 256) return launch_pw<float, 64>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
+    return launch_pw<float, 128>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);   // Cout <= 64 (LDS)
   } else if (dtype == FRL_BF16) {
     if (Cin <= 32) return launch_pw<bf16, 1>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
     if (Cin <= 64) return launch_pw<bf16, 2>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
     if (Cin <= 128) return launch_pw<bf16, 4>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
-    return launch_pw<bf16, 8>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
+    if (Cin <= 256) return launch_pw<bf16, 8>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
+    return launch_pw<bf16, 16>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);   // e.g. d(mix_head_B) at d = 128
   }
   return frl_fail(-2, "pw_conv: bad dtype");
 }

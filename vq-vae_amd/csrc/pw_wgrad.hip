@@ -18,7 +18,7 @@ template <typename T, int OBW, int IB>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(
     const T* __restrict__ dY, const T* __restrict__ Ymask, int mask_act, const T* __restrict__ X,
     float* __restrict__ slab, int64_t P, int Cout, int Cin, int64_t rows_per_wg, int HW, int Tn, int toff,
-    int use_tr) {
+    int use_tr, int64_t ldy) {                                // ldy = row stride of dY / Ymask (>= Cout: channel-slice calls)
   typedef typename DT<T>::frag_t frag_t;
   typedef typename std::conditional<sizeof(T) == 2, bf16x8, f32x4>::type vec_t;
   constexpr int FE = DT<T>::FE;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(
   const int64_t p_begin = (int64_t)blockIdx.x * rows_per_wg;
   int64_t p_end = p_begin + rows_per_wg;
   if (p_end > P) p_end = P;
-  const bool fastA = (Cout % VEC) == 0, fastB = (Cin % VEC) == 0;
+  const bool fastA = (Cout % VEC) == 0 && (ldy % VEC) == 0, fastB = (Cin % VEC) == 0;
   const bool fast = fastA && fastB;                          // 16-byte channel vectors: tiles are prefetched into registers
   const int64_t shift = (int64_t)toff * HW;
 
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(
       const int row = i / VPRA, c0 = (i % VPRA) * VEC;
       const int64_t p = p0 + row;
       const bool ok = i < WG_KP * VPRA && p < p_end && c0 < Cout;
-      const int64_t off = ok ? p * (int64_t)Cout + c0 : 0;
+      const int64_t off = ok ? p * ldy + c0 : 0;
       vec_t v = *reinterpret_cast<const vec_t*>(dY + off);
       if (!ok) v = vec_t{};
       ra[u] = v;
@@ -115,12 +115,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(
 #pragma unroll
         for (int e = 0; e < VEC; ++e) v[e] = 0.f;
         if (p < p_end && c0 < Cout) {
-          const T* src = dY + p * (int64_t)Cout + c0;
+          const T* src = dY + p * ldy + c0;
 #pragma unroll
           for (int e = 0; e < VEC; ++e)
             if (c0 + e < Cout) {
               v[e] = to_f32(src[e]);
-              if (Ymask != nullptr) v[e] *= act_bwd_from_y(to_f32(Ymask[p * (int64_t)Cout + c0 + e]), mask_act);
+              if (Ymask != nullptr) v[e] *= act_bwd_from_y(to_f32(Ymask[p * ldy + c0 + e]), mask_act);
             }
         }
         Vec<T>::store(ldsA + row * pitchA + c0, v);
@@ -255,7 +255,7 @@ static int wgrad_nwg(int64_t P) {
 
 template <typename T, int OBW, int IB>
 static int launch_wgrad(const void* dy, const void* ymask, int mask_act, const void* x, float* ws, int64_t P,
-                        int Cout, int Cin, int HW, int Tn, int toff, int use_tr, hipStream_t st) {
+                        int Cout, int Cin, int HW, int Tn, int toff, int use_tr, int64_t ldy, hipStream_t st) {
   const int nwg = wgrad_nwg(P);
   int64_t rows = (P + nwg - 1) / nwg;
   rows = (rows + WG_KP - 1) / WG_KP * WG_KP;
@@ -263,16 +263,16 @@ static int launch_wgrad(const void* dy, const void* ymask, int mask_act, const v
   auto kern = pw_wgrad_kernel<T, OBW, IB>;
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   FRL_LAUNCH(kern, dim3(nwg), dim3(256), lds, st, (const T*)dy, (const T*)ymask, mask_act, (const T*)x, ws,
-                     P, Cout, Cin, rows, HW, Tn, toff, use_tr);
+                     P, Cout, Cin, rows, HW, Tn, toff, use_tr, ldy);
   return frl_check_launch("pw_wgrad");
 }
 
 template <typename T>
 static int dispatch_wgrad(const void* dy, const void* ymask, int mask_act, const void* x, float* ws, int64_t P,
-                          int Cout, int Cin, int HW, int Tn, int toff, int use_tr, hipStream_t st) {
+                          int Cout, int Cin, int HW, int Tn, int toff, int use_tr, int64_t ldy, hipStream_t st) {
   const int ob = (Cout + 63) / 64;   // oc blocks per wave (4 waves x 16 rows)
   const int ib = (Cin + 15) / 16;
-#define WG_CASE(O, I) return launch_wgrad<T, O, I>(dy, ymask, mask_act, x, ws, P, Cout, Cin, HW, Tn, toff, use_tr, st)
+#define WG_CASE(O, I) return launch_wgrad<T, O, I>(dy, ymask, mask_act, x, ws, P, Cout, Cin, HW, Tn, toff, use_tr, ldy, st)
   if (ob <= 1) {
     if (ib <= 1) WG_CASE(1, 1);
     if (ib <= 2) WG_CASE(1, 2);
@@ -309,16 +309,24 @@ int frl_conv_tap_bwd_weight(const void* dy, const void* y, int act, const void* 
                             int dtype, void* ws, size_t ws_bytes, int flags, hipStream_t stream) {
   if (P <= 0) return frl_fail(-2, "bwd_weight: empty input");
   if (ws_bytes < frl_conv1x1_bwd_weight_workspace_bytes(P, Cin, Cout)) return frl_fail(-4, "bwd_weight: workspace too small");
-  if (Cout > 256) return frl_fail(-2, "bwd_weight: Cout > 256 unsupported");
   const void* ym = act != FRL_ACT_NONE ? y : nullptr;
   const int use_tr = (flags & 1) ? 0 : 1;
-  int rc;
-  if (dtype == FRL_F32) rc = dispatch_wgrad<float>(dy, ym, act, x, (float*)ws, P, Cout, Cin, HW, T, toff, 0, stream);
-  else if (dtype == FRL_BF16) rc = dispatch_wgrad<bf16>(dy, ym, act, x, (float*)ws, P, Cout, Cin, HW, T, toff, use_tr, stream);
-  else return frl_fail(-2, "bwd_weight: bad dtype");
-  if (rc) return rc;
-  const int64_t n = (int64_t)Cout * Cin + Cout;
-  launch_slab_reduce<float, WgradEpi>((const float*)ws, wgrad_nwg(P), n, WgradEpi{dw, dso, dsi, dbias, Cout, Cin, (flags & 2) ? 1 : 0}, stream);
+  const size_t esz = dtype == FRL_BF16 ? 2 : 4;
+  // output channels are processed in slices of <= 256 (accumulator budget of the kernel); a slice reads its columns of dY / y
+  // through the full row stride and fills its rows of dW / db
+  for (int oc0 = 0; oc0 < Cout; oc0 += 256) {
+    const int co = (Cout - oc0) < 256 ? (Cout - oc0) : 256;
+    const char* dyp = (const char*)dy + (size_t)oc0 * esz;
+    const char* ymp = ym ? (const char*)ym + (size_t)oc0 * esz : nullptr;
+    int rc;
+    if (dtype == FRL_F32) rc = dispatch_wgrad<float>(dyp, ymp, act, x, (float*)ws, P, co, Cin, HW, T, toff, 0, Cout, stream);
+    else if (dtype == FRL_BF16) rc = dispatch_wgrad<bf16>(dyp, ymp, act, x, (float*)ws, P, co, Cin, HW, T, toff, use_tr, Cout, stream);
+    else return frl_fail(-2, "bwd_weight: bad dtype");
+    if (rc) return rc;
+    const int64_t n = (int64_t)co * Cin + co;
+    launch_slab_reduce<float, WgradEpi>((const float*)ws, wgrad_nwg(P), n,
+                                        WgradEpi{dw + (int64_t)oc0 * dso, dso, dsi, dbias ? dbias + oc0 : nullptr, co, Cin, (flags & 2) ? 1 : 0}, stream);
+  }
   return frl_check_launch("slab_reduce");
 }
 
