@@ -170,6 +170,13 @@ def test_single_rank_rccl_reducer_path_matches_plain_trainer(golden_dir):
         tr.reducer = BucketedGradAllReduce([(n, p) for n, p in m.named_parameters() if p.requires_grad], force_hooks=True)
         assert tr.reducer.active and tr.hip_opt
         got = [tr.step(tiles[i])["loss"].item() for i in range(3)]
+        # the isfinite flag rides in the last gradient bucket: a bad batch is skipped through that route as well
+        before = {n: p.detach().clone() for n, p in m.named_parameters()}
+        bad = tiles[0].clone()
+        bad[0, 0, 0, 0, 0] = float("inf")
+        tr.step(bad)
+        assert all(torch.equal(p.detach(), before[n]) for n, p in m.named_parameters())
+        assert tr.opt.applied_and_skipped == (3, 1)
     finally:
         dist.destroy_process_group()
     assert got == ref, (got, ref)

@@ -34,11 +34,15 @@ class BucketedGradAllReduce:
         for bi, bucket in enumerate(self.buckets):
             n = sum(p.numel() for p in bucket)
             dev = bucket[0].device
-            self._flat.append(torch.zeros(n, dtype=torch.float32, device=dev))
+            # the LAST bucket carries one extra float: the "non-finite loss" flag of this rank rides along with the gradients,
+            # so agreeing on the isfinite guard costs no collective of its own
+            extra = 1 if bi == len(self.buckets) - 1 else 0
+            self._flat.append(torch.zeros(n + extra, dtype=torch.float32, device=dev))
             for p in bucket:
                 self._index[id(p)] = bi
         self.comm_stream = torch.cuda.Stream() if (self.buckets and self.buckets[0][0].is_cuda) else None
         self._hooks = []
+        self.flag_src = None                                # float32 [1] tensor (1 = this rank saw a non-finite loss), set per step
         self._tables: Dict[int, tuple] = {}                 # bucket -> (gradient pointer key, device desc table, device chunk table)
         self.on_gpu = bool(self.buckets) and self.buckets[0][0].is_cuda
         if self.world > 1 or force_hooks:
@@ -80,6 +84,8 @@ class BucketedGradAllReduce:
                     g = p.grad if p.grad is not None else torch.zeros_like(p)
                     flat[off:off + n].copy_(g.reshape(-1))
                     off += n
+                if bi == len(self.buckets) - 1:
+                    flat[off] = self.flag_src.reshape(()) if self.flag_src is not None else 0.0
                 flat.div_(self.world)
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if self.world > 1 else None
         self._works.append((bi, work))
@@ -97,20 +103,30 @@ class BucketedGradAllReduce:
             grads.append(g)
         self._keep = getattr(self, "_keep", {})
         self._keep[bi] = grads
-        key = tuple(g.data_ptr() if g is not None else 0 for g in grads)
+        last = bi == len(self.buckets) - 1
+        flag_ptr = self.flag_src.data_ptr() if (last and self.flag_src is not None) else 0
+        key = tuple(g.data_ptr() if g is not None else 0 for g in grads) + (flag_ptr,)
         tab = self._tables.get(bi)
         if tab is None or tab[0] != key:
-            off, recs = 0, []
+            off, recs, numels = 0, [], []
             for p, g in zip(bucket, grads):
                 recs.append(struct.pack("<QQq", g.data_ptr() if g is not None else 0, flat.data_ptr() + 4 * off, p.numel()))
+                numels.append(p.numel())
                 off += p.numel()
+            if last:                                        # flag slot (source NULL -> 0 when no flag was set)
+                recs.append(struct.pack("<QQq", flag_ptr, flat.data_ptr() + 4 * off, 1))
+                numels.append(1)
             raw = b"".join(recs)
-            chunks = tab[2] if tab is not None else ChunkTable([p.numel() for p in bucket], flat.device)
-            tab = (key, ctypes.create_string_buffer(raw, len(raw)), chunks)
+            chunks = tab[2] if tab is not None else ChunkTable(numels, flat.device)
+            tab = (key, ctypes.create_string_buffer(raw, len(raw)), chunks, len(numels))
             self._tables[bi] = tab
-        check(_lib.load().frl_multi_tensor_scale_copy(ctypes.cast(tab[1], ctypes.c_void_p), len(bucket), ctypes.c_void_p(tab[2].dev.data_ptr()),
+        check(_lib.load().frl_multi_tensor_scale_copy(ctypes.cast(tab[1], ctypes.c_void_p), tab[3], ctypes.c_void_p(tab[2].dev.data_ptr()),
                                                       ctypes.cast(tab[2].host_tensor_col, ctypes.c_void_p), tab[2].n, 1.0 / self.world,
                                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "frl_multi_tensor_scale_copy")
+
+    def flag_result(self) -> torch.Tensor:
+        """Mean over ranks of the flags handed in through `flag_src` (float32 [1] view, valid after finish()): 0 <=> every rank was fine."""
+        return self._flat[-1][-1:]
 
     def flat_grads(self) -> Dict[int, torch.Tensor]:
         """id(param) -> view of its averaged gradient inside the flat bucket (valid after finish(scatter=False))."""

@@ -74,8 +74,8 @@ class VQVAETrainer:
                 # step.py:1057-1074 (skip the batch on a non-finite loss) evaluated on the device: the flag gates the optimizer
                 # kernels, so the host never waits for the loss and keeps queueing the next step
                 ok = torch.isfinite(loss.detach()).float().reshape(1)
-                if self.reducer is not None and self.reducer.world > 1:
-                    dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank takes the same decision
+                if self.reducer is not None and self.reducer.active:
+                    self.reducer.flag_src = 1.0 - ok               # rides in the last gradient bucket: every rank takes the same decision
             elif not self._all_finite(loss):
                 self.skipped += 1
                 if self.reducer is not None:
@@ -89,6 +89,8 @@ class VQVAETrainer:
             if self.reducer is not None and self.reducer.active:   # averaged gradients are read straight from the all-reduce buckets
                 fg = self.reducer.flat_grads()
                 grads = [fg[id(p)] for p in self.opt.params]
+                if ok is not None:
+                    ok = (self.reducer.flag_result() == 0).float()   # 1 <=> no rank reported a non-finite loss
             out["grad_norm"] = self.opt.step(self.max_norm, grads, ok)
         else:
             out["grad_norm"] = torch.nn.utils.clip_grad_norm_(self.params, self.max_norm)
