@@ -164,7 +164,11 @@ def main():
         vq_bytes = n * (2 * args.emb_dim * s + 4) + args.codebook * args.emb_dim * 4
         out["vq_hbm"] = {"GB/s": round(vq_bytes / vq_ms / 1e6, 1), "frac": round(vq_bytes / vq_ms / 1e6 / HBM_PEAK_GBS, 4),
                          "ms": round(vq_ms, 4), "bytes": vq_bytes,
-                         "note": "event span of frl_vq_assign_fwd = prep + assign + float64 fix-up + reductions; per-kernel split in profiles/"}
+                         "note": "live HIP-event span of the whole frl_vq_assign_fwd call = prep + pack + assign + float64 fix-up + reductions"}
+        ku = profiled_kernel_us("vq_assign_kernel")
+        if ku is not None:                                    # the L2/argmin kernel alone, from the committed rocprofv3 kernel trace
+            out["vq_hbm"]["assign_kernel_rocprof"] = {"us": ku[0], "GB/s": round(vq_bytes / ku[0] / 1e3, 1),
+                                                      "frac": round(vq_bytes / ku[0] / 1e3 / HBM_PEAK_GBS, 4), "source": ku[1]}
         # --- conv MFMA: algorithmic dense FLOPs of the step (3 x forward) over the event time of every conv / TCN op
         conv_keys = [k for k in ksum if k.startswith(("conv", "tcn")) and k != "tcn_block_bwd.main"]
         conv_ms = sum(ksum[k][1] for k in conv_keys) / args.steps
@@ -182,6 +186,20 @@ def main():
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def profiled_kernel_us(substr):
+    """(average duration in us, file) of a kernel in the newest committed rocprofv3 kernel-trace summary, or None."""
+    try:
+        import csv
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats.csv")))[-1]
+        for r in csv.DictReader(open(f)):
+            if substr in r["name"]:
+                return round(float(r["avg_us"]), 1), os.path.relpath(f, ROOT)
+    except Exception:
+        pass
+    return None
 
 
 def pmc_traffic(name):
