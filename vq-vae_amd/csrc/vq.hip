@@ -584,8 +584,48 @@ __global__ __launch_bounds__(256) void vq_bwd_mfma_kernel(const bf16* __restrict
     for (int a = 0; a < RB; ++a)
 #pragma unroll
       for (int b = 0; b < CB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // register image of the NEXT 64-row tile (16-byte channel vectors): z, and on the first chunk g_out and z_q for the fused
+    // g_z = g_out + cz (z - z_q); requested behind the MFMAs of the current tile
+    constexpr int NV = (64 * (DP / 8) + 255) / 256;
+    const bool pre = fast && (ZQ != nullptr || gz == nullptr || kbase != 0);      // prefetch path: no codebook gather needed
+    const bool want_gz = (kbase == 0 && gz != nullptr);
+    bf16x8 rz[NV], rg[NV], rq[NV];
+    auto fetch = [&](int64_t p0) {
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const int i = tid + u * 256;
+        const int row = i / vpr, c0 = (i % vpr) * 8;
+        const int64_t n = p0 + row;
+        const bool ok = i < 64 * vpr && n < r1 && c0 < d;
+        const int64_t off = ok ? n * (int64_t)d + c0 : 0;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(Z + off);
+        if (!ok) v = bf16x8{};
+        rz[u] = v;
+        if (want_gz) {
+          rg[u] = gout != nullptr ? *reinterpret_cast<const bf16x8*>(gout + off) : bf16x8{};
+          rq[u] = *reinterpret_cast<const bf16x8*>(ZQ + off);
+        }
+      }
+    };
+    if (pre && r0 < r1) fetch(r0);
     for (int64_t p0 = r0; p0 < r1; p0 += 64) {
       __syncthreads();
+      if (pre) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+          const int i = tid + u * 256;
+          if (i >= 64 * vpr) continue;
+          const int row = i / vpr, c0 = (i % vpr) * 8;
+          const int64_t n = p0 + row;
+          if (want_gz && n < r1 && c0 < d) {
+            float ov[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (float)rg[u][e] + cz * ((float)rz[u][e] - (float)rq[u][e]);
+            Vec<bf16>::store(gz + n * (int64_t)d + c0, ov);
+          }
+          *reinterpret_cast<bf16x8*>(zt + row * PITCH + c0) = rz[u];
+        }
+      } else {
       // stage 64 rows of z (zero padded) and their indices; first chunk also writes g_z
       for (int i = tid; i < 64 * vpr; i += 256) {
         const int row = i / vpr, c0 = (i % vpr) * 8;
@@ -628,8 +668,10 @@ __global__ __launch_bounds__(256) void vq_bwd_mfma_kernel(const bf16* __restrict
         }
         Vec<bf16>::store(zt + row * PITCH + c0, zv);
       }
+      }
       if (tid < 64) it[tid] = (p0 + tid < r1) ? idx[p0 + tid] - kbase : -1;
       __syncthreads();
+      if (pre && p0 + 64 < r1) fetch(p0 + 64);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int pix0 = ks * 32 + 8 * kc;
