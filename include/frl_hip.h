@@ -125,10 +125,12 @@ int frl_tcn_block_bwd_fused(const void* x, const void* dy, const float* conv_w, 
 int frl_tcn_hot_supported(int T, int Cin, int Cout, int G, int dilation, int has_proj, int dtype);
 size_t frl_tcn_hot_fwd_workspace_bytes(void);
 size_t frl_tcn_hot_bwd_workspace_bytes(int64_t npix);
-int frl_tcn_hot_fwd(const void* x, const float* conv_w, const float* conv_b, const float* gn_w, const float* gn_b,
+/* drop_mask: NULL, or the training-mode Dropout1d mask of the block (tcn.py:53) as [B][HW][64] bf16 holding 0 or 1/(1-p) per
+ * (pixel series, channel): the temporal conv sees x .* mask, the residual path the untouched x (tcn.py:89-90). */
+int frl_tcn_hot_fwd(const void* x, const void* drop_mask, const float* conv_w, const float* conv_b, const float* gn_w, const float* gn_b,
                     const float* gate_w, const float* gate_b, void* y, int64_t npix, int HW, int dilation, float eps, void* ws,
                     size_t ws_bytes, frl_stream_t stream);
-int frl_tcn_hot_bwd(const void* x, const void* dy, const float* conv_w, const float* conv_b, const float* gn_w,
+int frl_tcn_hot_bwd(const void* x, const void* drop_mask, const void* dy, const float* conv_w, const float* conv_b, const float* gn_w,
                     const float* gn_b, const float* gate_w, const float* gate_b, void* dx, float* d_conv_w, float* d_conv_b,
                     float* d_gn_w, float* d_gn_b, float* d_gate_w, float* d_gate_b, int64_t npix, int HW, int dilation,
                     float eps, void* ws, size_t ws_bytes, frl_stream_t stream);

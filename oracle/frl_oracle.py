@@ -121,8 +121,9 @@ def edge_smooth_forward(state: State, x: torch.Tensor, rank: int = 4,
 
 
 def tcn_block_forward(state: State, x: torch.Tensor, dilation: int, num_groups: int,
-                      prefix: str) -> torch.Tensor:
-    """GatedResidualBlock.forward on [N, C, T] (dropout-free).
+                      prefix: str, drop_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GatedResidualBlock.forward on [N, C, T]; ``drop_mask`` [N, C] (0 or 1/(1-p)) is a given
+    Dropout1d realisation applied to the conv input only (tcn.py:53,89-90).
 
     Reference: frl/models/tcn.py:78-111.  ``gate`` is computed from the
     pre-ReLU normalised features; the residual projection exists only when
@@ -135,7 +136,8 @@ def tcn_block_forward(state: State, x: torch.Tensor, dilation: int, num_groups: 
         res = F.conv1d(x, state[prefix + "projection.weight"], state[prefix + "projection.bias"])
     else:
         res = x
-    out = F.conv1d(x, w, state[prefix + "conv.bias"], padding=pad, dilation=dilation)
+    xin = x if drop_mask is None else x * drop_mask.unsqueeze(-1)
+    out = F.conv1d(xin, w, state[prefix + "conv.bias"], padding=pad, dilation=dilation)
     out = group_norm(out, num_groups, state[prefix + "norm.weight"], state[prefix + "norm.bias"])
     gate = torch.sigmoid(F.conv1d(out, state[prefix + "gate.weight"], state[prefix + "gate.bias"]))
     out = F.relu(out)

@@ -292,6 +292,67 @@ def test_tcn_hot_kernels_match_oracle_and_generic(B, HW, dil):
         assert rel_err(hot[kk].reshape(ref.shape), gen[kk].reshape(ref.shape).cpu()) <= 2e-2, kk
 
 
+@pytest.mark.parametrize("B,HW,dil,p", [(2, 1024, 1, 0.5), (3, 100, 4, 0.25), (1, 77, 2, 0.1)])
+def test_tcn_hot_dropout1d_mask_matches_float64(B, HW, dil, p):
+    """Training-mode Dropout1d of the block (tcn.py:53): with a GIVEN keep/scale mask per (pixel series, channel) the hot kernels
+    (conv input = x .* mask, residual = x) must match float64 autograd of the same realisation, forward and backward."""
+    from frl_hip import ops
+    dtype, cin, cout, G, T = torch.bfloat16, 64, 64, 8, 5
+    g = torch.Generator().manual_seed(B * HW + dil)
+    pfx = "b."
+    st = {pfx + "conv.weight": torch.randn(cout, cin, 3, generator=g) / (3 * cin) ** 0.5, pfx + "conv.bias": torch.randn(cout, generator=g) * 0.1,
+          pfx + "norm.weight": torch.rand(cout, generator=g) + 0.5, pfx + "norm.bias": torch.randn(cout, generator=g) * 0.2,
+          pfx + "gate.weight": torch.randn(cout, cout, 1, generator=g) / cout ** 0.5, pfx + "gate.bias": torch.randn(cout, generator=g) * 0.1}
+    ref_st = {k: ((q(v, dtype) if k.endswith(("conv.weight", "gate.weight")) else v.double()).requires_grad_(True)) for k, v in st.items()}
+    x = q(torch.randn(B, T, HW, cin, generator=g), dtype).requires_grad_(True)
+    mask = q(((torch.rand(B, HW, cin, generator=g) >= p).float() / (1.0 - p)), dtype)            # bf16-rounded scale, as the module builds it
+    # the kernel rounds x .* mask to bf16 before the MFMA: mirror that in the reference (straight-through for the gradient)
+    xm = x * mask.unsqueeze(1)
+    xm = xm + (q(xm.detach(), dtype) - xm.detach())
+    xr = x.permute(0, 2, 3, 1).reshape(B * HW, cin, T)
+    xmr = xm.permute(0, 2, 3, 1).reshape(B * HW, cin, T)
+    w = ref_st[pfx + "conv.weight"]
+    out = torch.nn.functional.conv1d(xmr, w, ref_st[pfx + "conv.bias"], padding=dil, dilation=dil)
+    out = O.group_norm(out, G, ref_st[pfx + "norm.weight"], ref_st[pfx + "norm.bias"])
+    gate = torch.sigmoid(torch.nn.functional.conv1d(out, ref_st[pfx + "gate.weight"], ref_st[pfx + "gate.bias"]))
+    yr = (gate * torch.relu(out) + (1 - gate) * xr).reshape(B, HW, cout, T).permute(0, 3, 1, 2)
+    # same thing through the oracle's own block with the mask argument (no bf16 rounding of the product): close to the above
+    y_or = O.tcn_block_forward({k: v.detach() for k, v in ref_st.items()}, xr.detach(), dil, G, pfx, drop_mask=mask.reshape(B * HW, cin))
+    assert rel_err(y_or.reshape(B, HW, cout, T).permute(0, 3, 1, 2), yr.detach()) <= 2e-2
+    dy = q(torch.randn(B, T, HW, cout, generator=g), dtype)
+    yr.backward(dy)
+    dev = {k: v.float().to(DEV) for k, v in st.items()}
+    args = (dev[pfx + "conv.weight"], dev[pfx + "conv.bias"], dev[pfx + "norm.weight"], dev[pfx + "norm.bias"], dev[pfx + "gate.weight"], dev[pfx + "gate.bias"], None, None)
+    xd, dyd, md = x.detach().to(dtype).to(DEV), dy.to(dtype).to(DEV), mask.to(dtype).to(DEV)
+    y = ops.tcn_block_fwd(xd, *args, dil, G, drop_mask=md)
+    assert rel_err(y.float(), yr.detach()) <= 8e-3
+    y0 = ops.tcn_block_fwd(xd, *args, dil, G)
+    assert rel_err(y.float(), y0.float().cpu()) > 1e-2                                            # the mask really changes the output
+    gr = ops.tcn_block_bwd(xd, dyd, *args, dil, G, drop_mask=md)
+    assert rel_err(gr["dx"].float(), x.grad) <= 2e-2
+    names = dict(conv_w="conv.weight", conv_b="conv.bias", gn_w="norm.weight", gn_b="norm.bias", gate_w="gate.weight", gate_b="gate.bias")
+    for kk, nm in names.items():
+        ref = ref_st[pfx + nm].grad
+        assert rel_err(gr[kk].reshape(ref.shape), ref) <= 2e-2, kk
+    with pytest.raises(NotImplementedError):
+        ops.tcn_block_fwd(xd[:, :4].contiguous(), *args, dil, G, drop_mask=md)                     # T != 5: generic kernels, no dropout
+
+
+def test_channel_scale_dropout2d():
+    """Dropout2d of the type encoder (conv2d_encoder.py:74,142-148): y = x * scale[b, c], gradient dx = dy * scale[b, c]."""
+    from frl_hip import functional as Fh
+    g = torch.Generator().manual_seed(5)
+    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 8e-3)):
+        x = q(torch.randn(3, 8, 8, 16, generator=g), dtype)
+        sc = q((torch.rand(3, 16, generator=g) >= 0.3).float() / 0.7, dtype)
+        xd = x.to(dtype).to(DEV).requires_grad_(True)
+        y = Fh.ChannelScaleFn.apply(xd, sc.to(dtype).to(DEV))
+        assert rel_err(y.float(), x * sc.view(3, 1, 1, 16)) <= tol
+        dy = q(torch.randn(3, 8, 8, 16, generator=g), dtype)
+        y.backward(dy.to(dtype).to(DEV))
+        assert rel_err(xd.grad.float(), dy * sc.view(3, 1, 1, 16)) <= tol
+
+
 @pytest.mark.parametrize("P,cz,use_mask", [(4096, 64, False), (5000, 12, True), (333, 12, False), (1000, 32, True), (130, 64, True)])
 def test_fused_decoder_mse(P, cz, use_mask):
     """Fused decoder + L2 loss (bf16) vs float64 autograd of the same chain, and vs the modular kernels."""

@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int it = 0; it < 5; ++it) {
     CK(hipEventRecord(e0, 0));
-    int rc = frl_tcn_hot_bwd(x, dy, dwc, b0, gam, bet, dwg, b1, dx, g[0], g[1], g[2], g[3], g[4], g[5], npix, HW, dil, 1e-5f, ws, wsb, 0);
+    int rc = frl_tcn_hot_bwd(x, nullptr, dy, dwc, b0, gam, bet, dwg, b1, dx, g[0], g[1], g[2], g[3], g[4], g[5], npix, HW, dil, 1e-5f, ws, wsb, 0);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("iter %d rc=%d  %.1f us (pack + bwd + slab reduce)\n", it, rc, ms * 1e3f);

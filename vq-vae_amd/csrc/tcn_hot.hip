@@ -87,6 +87,20 @@ __device__ __forceinline__ void th_stats(const f32x4 (&acc)[TH_T][4], float eps,
   }
 }
 
+// element-wise products of bf16 images (Dropout1d mask applied to the conv input / its gradient)
+__device__ __forceinline__ frag8 th_mul8(const frag8& a, const frag8& b) {
+  frag8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)a[j] * (float)b[j]);
+  return o;
+}
+__device__ __forceinline__ Tile2 th_mul(const Tile2& a, const Tile2& b) {
+  Tile2 o;
+  o.f[0] = th_mul8(a.f[0], b.f[0]);
+  o.f[1] = th_mul8(a.f[1], b.f[1]);
+  return o;
+}
+
 __device__ __forceinline__ Tile2 th_load(const bf16* __restrict__ p) {
   Tile2 t;
   t.f[0] = *reinterpret_cast<const frag8*>(p);
@@ -101,8 +115,10 @@ __device__ __forceinline__ void th_store(bf16* __restrict__ p, const Tile2& t) {
 // =============================================================================================================
 // forward
 // =============================================================================================================
-template <int DIL>
-__global__ __launch_bounds__(256, 2) void tcn_hot_fwd_kernel(const bf16* __restrict__ X, const frag8* __restrict__ Wpk,
+// MASK: training-mode Dropout1d of the block (tcn.py:53): the conv sees x .* M, the residual path the untouched x; M [B*HW][64] holds
+// 0 or 1/(1-p) per (pixel series, channel).  The MASK = false instantiation is the kernel without any trace of it.
+template <int DIL, bool MASK>
+__global__ __launch_bounds__(256, 2) void tcn_hot_fwd_kernel(const bf16* __restrict__ X, const bf16* __restrict__ M, const frag8* __restrict__ Wpk,
                                                              const float* __restrict__ bc, const float* __restrict__ gn_w,
                                                              const float* __restrict__ gn_b, const float* __restrict__ bg,
                                                              bf16* __restrict__ Y, int64_t npix, int HW, float eps) {
@@ -143,7 +159,15 @@ __global__ __launch_bounds__(256, 2) void tcn_hot_fwd_kernel(const bf16* __restr
 #pragma unroll
       for (int t = 0; t < TH_T; ++t) acc[t][m] = cb;
     }
-    th_conv<DIL>(acc, x, wl_conv, lane);
+    if constexpr (MASK) {
+      const Tile2 mk = th_load(M + pidx * 64 + 16 * kc);
+      Tile2 xc[TH_T];
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t) xc[t] = th_mul(x[t], mk);
+      th_conv<DIL>(acc, xc, wl_conv, lane);
+    } else {
+      th_conv<DIL>(acc, x, wl_conv, lane);
+    }
     float mean[2], rstd[2];
     th_stats(acc, eps, mean, rstd);
     const float nm[2] = {-mean[0] * rstd[0], -mean[1] * rstd[1]};  // xhat = acc * rstd + nm
@@ -487,8 +511,8 @@ __device__ __forceinline__ Tile2 th_get(const bf16* tile, int prow, int kc) {
   return t;
 }
 
-template <int DIL>
-__global__ __launch_bounds__(512, 2) void tcn_hot_bwd2_kernel(const bf16* __restrict__ X, const bf16* __restrict__ DY,
+template <int DIL, bool MASK>
+__global__ __launch_bounds__(512, 2) void tcn_hot_bwd2_kernel(const bf16* __restrict__ X, const bf16* __restrict__ M, const bf16* __restrict__ DY,
                                                               const frag8* __restrict__ Wpk, const float* __restrict__ bc,
                                                               const float* __restrict__ gn_w, const float* __restrict__ gn_b,
                                                               const float* __restrict__ bg, bf16* DX, float* __restrict__ slab,
@@ -550,10 +574,12 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd2_kernel(const bf16* __rest
   const int nwt = (int)((npix + 63) >> 6);
   const int64_t tstride = (int64_t)HW * 64;
   // this lane's pixel of workgroup tile `wt`: row offset (elements) of its time step 0, or of the last pixel when out of range
+  unsigned pix_cur = 0;                                          // clamped pixel index of the current tile (mask row)
   auto pix_off = [&](int wt, bool& ok) -> int64_t {
     unsigned pidx = (unsigned)wt * 64u + (unsigned)prow;
     ok = pidx < (unsigned)npix;
     if (!ok) pidx = (unsigned)npix - 1u;
+    pix_cur = pidx;
     const unsigned b = pidx / (unsigned)HW, hw = pidx - b * (unsigned)HW;
     return ((int64_t)b * TH_T * HW + hw) * 64;
   };
@@ -568,7 +594,7 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd2_kernel(const bf16* __rest
     frag8 dyo[TH_T];
 #pragma unroll
     for (int t = 0; t < TH_T; ++t) x[t] = th_load(X + off + 16 * kc + t * tstride);
-    frag8 xo[TH_T];
+    frag8 xo[TH_T], m_own = frag8{};
     f32x4 xh[TH_T][2];
     float mean, rstd;
     {
@@ -577,6 +603,14 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd2_kernel(const bf16* __rest
         const f32x4 cb = tcb[mm];
 #pragma unroll
         for (int t = 0; t < TH_T; ++t) xh[t][mm] = cb;
+      }
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t) xo[t] = h ? x[t].f[1] : x[t].f[0];     // residual path: the untouched x
+      if constexpr (MASK) {                                                  // conv path: x .* M
+        const Tile2 mk = th_load(M + (int64_t)pix_cur * 64 + 16 * kc);
+        m_own = h ? mk.f[1] : mk.f[0];
+#pragma unroll
+        for (int t = 0; t < TH_T; ++t) x[t] = th_mul(x[t], mk);
       }
 #pragma unroll
       for (int k = 0; k < 3; ++k)
@@ -589,8 +623,6 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd2_kernel(const bf16* __rest
             for (int t = 0; t < TH_T; ++t)
               if (th_valid<DIL>(t, k)) xh[t][mm] = mfma16(wf, x[t + (k - 1) * DIL].f[s], xh[t][mm]);
           }
-#pragma unroll
-      for (int t = 0; t < TH_T; ++t) xo[t] = h ? x[t].f[1] : x[t].f[0];
     }
     // dy is requested only now (its registers would otherwise sit next to x, the conv accumulators and the hoisted weight
     // fragments): the statistics / n[t] pass below covers most of the latency
@@ -721,19 +753,22 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd2_kernel(const bf16* __rest
 #pragma unroll
     for (int t = 0; t < TH_T; ++t) {
       *reinterpret_cast<frag8*>(bufA + t * TH_TILE + prow * TH_PITCH + co) = dcf[t];
-      *reinterpret_cast<frag8*>(bufB + t * TH_TILE + prow * TH_PITCH + co) = xo[t];
+      *reinterpret_cast<frag8*>(bufB + t * TH_TILE + prow * TH_PITCH + co) = MASK ? th_mul8(xo[t], m_own) : xo[t];   // the conv input
     }
     __syncthreads();                                               // D
     TH_ST2(7);
     // ---------------- dx[t'] = sum_k W_k^T dconv[t' - (k-1) d] + dres[t'] (this wave's 8 channels per lane) ----------------
     {
       f32x4 dxa[TH_T][2];
+      frag8 drm[TH_T];                                               // (MASK) dres is added after the mask scales the conv path
 #pragma unroll
       for (int t = 0; t < TH_T; ++t) {
         const frag8 drt = *reinterpret_cast<const frag8*>(dxp + t * tstride);
+        drm[t] = drt;
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm)
-          dxa[t][mm] = f32x4{(float)drt[4 * mm], (float)drt[4 * mm + 1], (float)drt[4 * mm + 2], (float)drt[4 * mm + 3]};
+          dxa[t][mm] = MASK ? f32x4{0.f, 0.f, 0.f, 0.f}
+                            : f32x4{(float)drt[4 * mm], (float)drt[4 * mm + 1], (float)drt[4 * mm + 2], (float)drt[4 * mm + 3]};
       }
       Tile2 dct[TH_T];
 #pragma unroll
@@ -754,7 +789,7 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd2_kernel(const bf16* __rest
         for (int t = 0; t < TH_T; ++t) {
           float y[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) y[e] = dxa[t][e >> 2][e & 3];
+          for (int e = 0; e < 8; ++e) y[e] = MASK ? fmaf((float)m_own[e], dxa[t][e >> 2][e & 3], (float)drm[t][e]) : dxa[t][e >> 2][e & 3];
           *reinterpret_cast<frag8*>(dxp + t * tstride) = th_pack8(y);
         }
       }
@@ -869,24 +904,38 @@ static constexpr size_t TH_FWD_LDS = (size_t)32 * 64 * sizeof(frag8) + 4 * 64 * 
 static constexpr size_t TH_BWD_LDS = TH_PACK_BYTES + (size_t)(4 * 64 + 4 * 2 * 64) * sizeof(float) + (size_t)2 * TH_T * TH_TILE * sizeof(bf16);
 
 template <int DIL>
-static int th_launch_fwd(const void* x, const frag8* pk, const float* bc, const float* gw, const float* gb, const float* bg, void* y,
-                         int64_t npix, int HW, float eps, hipStream_t st) {
-  auto kern = tcn_hot_fwd_kernel<DIL>;
-  FRL_LAUNCH(kern, dim3(th_fwd_grid(npix)), dim3(256), TH_FWD_LDS, st, (const bf16*)x, pk, bc, gw, gb, bg, (bf16*)y, npix, HW, eps);
+static int th_launch_fwd(const void* x, const void* mask, const frag8* pk, const float* bc, const float* gw, const float* gb, const float* bg,
+                         void* y, int64_t npix, int HW, float eps, hipStream_t st) {
+  if (mask != nullptr) {
+    FRL_LAUNCH((tcn_hot_fwd_kernel<DIL, true>), dim3(th_fwd_grid(npix)), dim3(256), TH_FWD_LDS, st, (const bf16*)x, (const bf16*)mask, pk, bc, gw,
+               gb, bg, (bf16*)y, npix, HW, eps);
+  } else {
+    FRL_LAUNCH((tcn_hot_fwd_kernel<DIL, false>), dim3(th_fwd_grid(npix)), dim3(256), TH_FWD_LDS, st, (const bf16*)x, (const bf16*)nullptr, pk, bc,
+               gw, gb, bg, (bf16*)y, npix, HW, eps);
+  }
   return 0;
 }
 template <int DIL>
-static int th_launch_bwd(const void* x, const void* dy, const frag8* pk, const float* bc, const float* gw, const float* gb, const float* bg,
-                         void* dx, float* slab, unsigned grid, int64_t npix, int HW, float eps, hipStream_t st) {
+static int th_launch_bwd(const void* x, const void* mask, const void* dy, const frag8* pk, const float* bc, const float* gw, const float* gb,
+                         const float* bg, void* dx, float* slab, unsigned grid, int64_t npix, int HW, float eps, hipStream_t st) {
 #ifdef TH_BWD_V1
+  if (mask != nullptr) return frl_fail(-2, "tcn_hot_bwd (4-wave diagnostic build): dropout mask unsupported");
   auto kern = tcn_hot_bwd_kernel<DIL>;
-  const unsigned nthr = 256;
-#else
-  auto kern = tcn_hot_bwd2_kernel<DIL>;
-  const unsigned nthr = 512;
-#endif
   FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TH_BWD_LDS));
-  FRL_LAUNCH(kern, dim3(grid), dim3(nthr), TH_BWD_LDS, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx, slab, npix, HW, eps);
+  FRL_LAUNCH(kern, dim3(grid), dim3(256), TH_BWD_LDS, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx, slab, npix, HW, eps);
+#else
+  if (mask != nullptr) {
+    auto kern = tcn_hot_bwd2_kernel<DIL, true>;
+    FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TH_BWD_LDS));
+    FRL_LAUNCH(kern, dim3(grid), dim3(512), TH_BWD_LDS, st, (const bf16*)x, (const bf16*)mask, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx,
+               slab, npix, HW, eps);
+  } else {
+    auto kern = tcn_hot_bwd2_kernel<DIL, false>;
+    FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TH_BWD_LDS));
+    FRL_LAUNCH(kern, dim3(grid), dim3(512), TH_BWD_LDS, st, (const bf16*)x, (const bf16*)nullptr, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx,
+               slab, npix, HW, eps);
+  }
+#endif
   return 0;
 }
 
@@ -900,8 +949,9 @@ int frl_tcn_hot_supported(int T, int Cin, int Cout, int G, int dilation, int has
 size_t frl_tcn_hot_fwd_workspace_bytes(void) { return TH_PACK_BYTES; }
 size_t frl_tcn_hot_bwd_workspace_bytes(int64_t npix) { return (size_t)th_bwd_grid(npix) * TH_SLAB * sizeof(float) + 256 + TH_PACK_BYTES; }
 
-// x, y [B][5][HW][64] bf16; parameters float32 in the reference layouts (conv_w [64][64][3], gate_w [64][64])
-int frl_tcn_hot_fwd(const void* x, const float* conv_w, const float* conv_b, const float* gn_w, const float* gn_b, const float* gate_w,
+// x, y [B][5][HW][64] bf16; parameters float32 in the reference layouts (conv_w [64][64][3], gate_w [64][64]); drop_mask: NULL, or the
+// Dropout1d mask [B][HW][64] bf16 (0 or 1/(1-p)) of a training-mode block (conv input = x .* mask, residual = x; tcn.py:53,89-90)
+int frl_tcn_hot_fwd(const void* x, const void* drop_mask, const float* conv_w, const float* conv_b, const float* gn_w, const float* gn_b, const float* gate_w,
                     const float* gate_b, void* y, int64_t npix, int HW, int dilation, float eps, void* ws, size_t ws_bytes,
                     hipStream_t stream) {
   if (npix <= 0 || HW <= 0) return frl_fail(-2, "tcn_hot_fwd: empty input");
@@ -909,16 +959,16 @@ int frl_tcn_hot_fwd(const void* x, const float* conv_w, const float* conv_b, con
   frag8* pk = (frag8*)ws;
   FRL_LAUNCH(tcn_hot_pack_kernel, dim3(32), dim3(256), 0, stream, pk, conv_w, gate_w);
   int rc = -2;
-  if (dilation == 1) rc = th_launch_fwd<1>(x, pk, conv_b, gn_w, gn_b, gate_b, y, npix, HW, eps, stream);
-  else if (dilation == 2) rc = th_launch_fwd<2>(x, pk, conv_b, gn_w, gn_b, gate_b, y, npix, HW, eps, stream);
-  else if (dilation == 4) rc = th_launch_fwd<4>(x, pk, conv_b, gn_w, gn_b, gate_b, y, npix, HW, eps, stream);
+  if (dilation == 1) rc = th_launch_fwd<1>(x, drop_mask, pk, conv_b, gn_w, gn_b, gate_b, y, npix, HW, eps, stream);
+  else if (dilation == 2) rc = th_launch_fwd<2>(x, drop_mask, pk, conv_b, gn_w, gn_b, gate_b, y, npix, HW, eps, stream);
+  else if (dilation == 4) rc = th_launch_fwd<4>(x, drop_mask, pk, conv_b, gn_w, gn_b, gate_b, y, npix, HW, eps, stream);
   else return frl_fail(-2, "tcn_hot_fwd: dilation must be 1, 2 or 4");
   if (rc) return rc;
   return frl_check_launch("tcn_hot_fwd");
 }
 
-// one launch: dx [B][5][HW][64] bf16 and all parameter gradients (float32, reference layouts)
-int frl_tcn_hot_bwd(const void* x, const void* dy, const float* conv_w, const float* conv_b, const float* gn_w, const float* gn_b,
+// one launch: dx [B][5][HW][64] bf16 and all parameter gradients (float32, reference layouts); drop_mask as in the forward
+int frl_tcn_hot_bwd(const void* x, const void* drop_mask, const void* dy, const float* conv_w, const float* conv_b, const float* gn_w, const float* gn_b,
                     const float* gate_w, const float* gate_b, void* dx, float* d_conv_w, float* d_conv_b, float* d_gn_w, float* d_gn_b,
                     float* d_gate_w, float* d_gate_b, int64_t npix, int HW, int dilation, float eps, void* ws, size_t ws_bytes,
                     hipStream_t stream) {
@@ -930,9 +980,9 @@ int frl_tcn_hot_bwd(const void* x, const void* dy, const float* conv_w, const fl
   frag8* pk = reinterpret_cast<frag8*>(reinterpret_cast<char*>(ws) + (((size_t)grid * TH_SLAB * sizeof(float) + 255) / 256) * 256);
   FRL_LAUNCH(tcn_hot_pack_kernel, dim3(32), dim3(256), 0, stream, pk, conv_w, gate_w);
   int rc = -2;
-  if (dilation == 1) rc = th_launch_bwd<1>(x, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
-  else if (dilation == 2) rc = th_launch_bwd<2>(x, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
-  else if (dilation == 4) rc = th_launch_bwd<4>(x, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
+  if (dilation == 1) rc = th_launch_bwd<1>(x, drop_mask, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
+  else if (dilation == 2) rc = th_launch_bwd<2>(x, drop_mask, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
+  else if (dilation == 4) rc = th_launch_bwd<4>(x, drop_mask, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
   else return frl_fail(-2, "tcn_hot_bwd: dilation must be 1, 2 or 4");
   if (rc) return rc;
   launch_slab_reduce<float, ThEpi>((const float*)slab, (int)grid, (int64_t)TH_SLAB, ThEpi{d_conv_w, d_gate_w, d_conv_b, d_gate_b, d_gn_w, d_gn_b},

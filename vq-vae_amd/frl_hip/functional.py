@@ -139,10 +139,11 @@ class TcnBlockFn(Function):
     """Fused GatedResidualBlock on x [B,T,HW..,Cin]."""
 
     @staticmethod
-    def forward(ctx, x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, dilation, groups, eps):
+    def forward(ctx, x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, dilation, groups, eps, drop_mask=None):
         pw = None if proj_w is None else proj_w.reshape(proj_w.shape[0], proj_w.shape[1])
-        y = ops.tcn_block_fwd(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, pw, proj_b, dilation, groups, eps)
+        y = ops.tcn_block_fwd(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, pw, proj_b, dilation, groups, eps, drop_mask=drop_mask)
         ctx.cfg = (dilation, groups, eps)
+        ctx.drop_mask = drop_mask
         ctx.save_for_backward(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b)
         return y
 
@@ -152,10 +153,11 @@ class TcnBlockFn(Function):
         x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b = ctx.saved_tensors
         dilation, groups, eps = ctx.cfg
         pw = None if proj_w is None else proj_w.reshape(proj_w.shape[0], proj_w.shape[1])
-        g = ops.tcn_block_bwd(x, _c(dy), conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, pw, proj_b, dilation, groups, eps)
+        g = ops.tcn_block_bwd(x, _c(dy), conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, pw, proj_b, dilation, groups, eps,
+                              drop_mask=ctx.drop_mask)
         dpw = g["proj_w"].reshape(proj_w.shape) if proj_w is not None else None
         return (g["dx"] if ctx.needs_input_grad[0] else None, g["conv_w"], g["conv_b"], g["gn_w"], g["gn_b"], g["gate_w"],
-                g["gate_b"], dpw, g.get("proj_b"), None, None, None)
+                g["gate_b"], dpw, g.get("proj_b"), None, None, None, None)
 
 
 class FilmFn(Function):
@@ -171,6 +173,26 @@ class FilmFn(Function):
     def backward(ctx, dout):
         h, gamma = ctx.saved_tensors
         return ops.film_modulate_bwd(_c(dout), h, gamma)
+
+
+class ChannelScaleFn(Function):
+    """y[b, r, c] = x[b, r, c] * scale[b, c]  (Dropout2d mask on NHWC rows; the FiLM kernel with a single 'pixel' per sample)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        b, c = scale.shape
+        ctx.save_for_backward(scale)
+        zero = torch.zeros_like(scale)
+        ctx.zero = zero
+        return ops.film_modulate_fwd(x.reshape(b, -1, 1, c), scale.reshape(b, 1, c), zero.reshape(b, 1, c)).reshape(x.shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (scale,) = ctx.saved_tensors
+        b, c = scale.shape
+        dy = _c(dy)
+        return ops.film_modulate_fwd(dy.reshape(b, -1, 1, c), scale.reshape(b, 1, c), ctx.zero.reshape(b, 1, c)).reshape(dy.shape), None
 
 
 class VQFn(Function):

@@ -81,15 +81,21 @@ class GroupNormParams(nn.Module):
         return Fh.group_norm(x, self.weight, self.bias, self.num_groups, self.eps, relu)
 
 
-def channel_dropout(x: torch.Tensor, p: float, training: bool, group_rows: int) -> torch.Tensor:
-    """Dropout2d / Dropout1d semantics on NHWC rows: zero whole channels per sample (group of `group_rows` rows).
+def dropout_mask(shape, p: float, like: torch.Tensor) -> torch.Tensor:
+    """Bernoulli keep-mask scaled by 1/(1-p) (torch.nn.Dropout*d semantics), in the dtype / on the device of `like`."""
+    keep = torch.rand(shape, device=like.device) >= p
+    return (keep.float() / (1.0 - p)).to(like.dtype)
 
-    p == 0 or eval -> identity (the parity configuration).  p > 0 in training is not implemented in HIP yet and is
-    refused rather than silently skipped.
-    """
+
+def channel_dropout(x: torch.Tensor, p: float, training: bool, group_rows: int) -> torch.Tensor:
+    """Dropout2d semantics on NHWC rows [B, ..., C]: whole channel maps of a sample are zeroed, the rest scaled by 1/(1-p)
+    (conv2d_encoder.py:74,142-148).  p == 0 or eval -> identity (the parity configuration)."""
     if not training or p <= 0.0:
         return x
-    raise NotImplementedError("channel dropout with p > 0 in training mode: configure dropout 0.0 (see DESIGN.md)")
+    if p >= 1.0:
+        return torch.zeros_like(x)
+    b, c = x.shape[0], x.shape[-1]
+    return Fh.ChannelScaleFn.apply(x, dropout_mask((b, c), p, x))
 
 
 class Conv2DEncoder(nn.Module):
@@ -203,11 +209,15 @@ class GatedResidualBlock(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x [B,T,HW..,Cin] -> [B,T,HW..,Cout]."""
-        channel_dropout(x, self.dropout.p, self.training, 1)
+        # Dropout1d on the conv input only (tcn.py:53,89-90): one keep/scale value per (pixel series, channel); the fused kernels
+        # take it as a [B, HW.., C] mask so that the residual path still sees the untouched x
+        mask = None
+        if self.training and self.dropout.p > 0.0:
+            mask = dropout_mask((x.shape[0],) + tuple(x.shape[2:]), min(self.dropout.p, 1.0 - 1e-6), x)
         pw = self.projection.weight if self.needs_projection else None
         pb = self.projection.bias if self.needs_projection else None
         return Fh.TcnBlockFn.apply(x, self.conv.weight, self.conv.bias, self.norm.weight, self.norm.bias, self.gate.weight,
-                                   self.gate.bias, pw, pb, self.dilation, self.norm.num_groups, self.norm.eps)
+                                   self.gate.bias, pw, pb, self.dilation, self.norm.num_groups, self.norm.eps, mask)
 
 
 class TCNEncoder(nn.Module):

@@ -404,16 +404,29 @@ def edge_smooth_bwd(d_smoothed, x, a_soft, b_soft, rank: int, coarse_dilation: i
 # fused TCN block (csrc/tcn_fwd.hip, tcn_bwd.hip); x [B,T,HW..,Cin]
 # ----------------------------------------------------------------------------------------------
 @_timed("tcn_block_fwd")
+def _check_drop_mask(drop_mask, x, hot: bool):
+    if drop_mask is None:
+        return
+    if not hot:
+        raise NotImplementedError("TCN Dropout1d (p > 0, training) is implemented for the hot configuration only "
+                                  "(bf16, 64 channels, T = 5, 8 groups, dilation 1/2/4); configure phase_tcn dropout 0.0 otherwise")
+    b, t, c = x.shape[0], x.shape[1], x.shape[-1]
+    if drop_mask.dtype != x.dtype or not drop_mask.is_contiguous() or drop_mask.numel() != x.numel() // t:
+        raise ValueError("drop_mask must be a contiguous [B, HW.., C] tensor of x's dtype")
+
+
 def tcn_block_fwd(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, dilation: int, groups: int,
-                  eps: float = 1e-5, allow_hot: bool = True):
+                  eps: float = 1e-5, allow_hot: bool = True, drop_mask=None):
     b, t, cin = x.shape[0], x.shape[1], x.shape[-1]
     cout = conv_w.shape[0]
     hw = x.numel() // (b * t * cin)
     y = torch.empty(x.shape[:-1] + (cout,), dtype=x.dtype, device=x.device)
     lib = _lib.load()
-    if allow_hot and lib.frl_tcn_hot_supported(t, cin, cout, groups, dilation, int(proj_w is not None), _dt(x)):
+    hot = bool(allow_hot and lib.frl_tcn_hot_supported(t, cin, cout, groups, dilation, int(proj_w is not None), _dt(x)))
+    _check_drop_mask(drop_mask, x, hot)
+    if hot:
         ws = workspace(lib.frl_tcn_hot_fwd_workspace_bytes(), x.device)
-        check(lib.frl_tcn_hot_fwd(_p(x), _p(_f32(conv_w, "conv_w")), _p(conv_b), _p(gn_w), _p(gn_b),
+        check(lib.frl_tcn_hot_fwd(_p(x), _p(drop_mask), _p(_f32(conv_w, "conv_w")), _p(conv_b), _p(gn_w), _p(gn_b),
                                   _p(_f32(gate_w.reshape(cout, cout), "gate_w")), _p(gate_b), _p(y), b * hw, hw, dilation, float(eps),
                                   _p(ws), ws.numel(), _stream()), "frl_tcn_hot_fwd")
         return y
@@ -427,7 +440,7 @@ def tcn_block_fwd(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b,
 
 @_timed("tcn_block_bwd")
 def tcn_block_bwd(x, dy, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, dilation: int, groups: int,
-                  eps: float = 1e-5, allow_fused: bool = True, allow_hot: bool = True):
+                  eps: float = 1e-5, allow_fused: bool = True, allow_hot: bool = True, drop_mask=None):
     """Returns dict(dx, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b[, proj_w, proj_b]) gradients."""
     b, t, cin = x.shape[0], x.shape[1], x.shape[-1]
     cout = conv_w.shape[0]
@@ -435,13 +448,15 @@ def tcn_block_bwd(x, dy, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, pro
     npix = b * hw
     lib = _lib.load()
     dev = x.device
-    if allow_fused and allow_hot and lib.frl_tcn_hot_supported(t, cin, cout, groups, dilation, int(proj_w is not None), _dt(x)):
+    hot = bool(allow_fused and allow_hot and lib.frl_tcn_hot_supported(t, cin, cout, groups, dilation, int(proj_w is not None), _dt(x)))
+    _check_drop_mask(drop_mask, x, hot)
+    if hot:
         dx = torch.empty_like(x)
         g = {k: torch.empty_like(v, dtype=torch.float32) for k, v in
              dict(conv_w=conv_w, conv_b=conv_b, gn_w=gn_w, gn_b=gn_b, gate_w=gate_w, gate_b=gate_b).items()}
         ws = workspace(lib.frl_tcn_hot_bwd_workspace_bytes(npix), dev)
         with span("tcn_block_bwd.main"):
-            check(lib.frl_tcn_hot_bwd(_p(x), _p(dy), _p(conv_w), _p(conv_b), _p(gn_w), _p(gn_b), _p(gate_w.reshape(cout, cout)), _p(gate_b),
+            check(lib.frl_tcn_hot_bwd(_p(x), _p(drop_mask), _p(dy), _p(conv_w), _p(conv_b), _p(gn_w), _p(gn_b), _p(gate_w.reshape(cout, cout)), _p(gate_b),
                                       _p(dx), _p(g["conv_w"]), _p(g["conv_b"]), _p(g["gn_w"]), _p(g["gn_b"]), _p(g["gate_w"]),
                                       _p(g["gate_b"]), npix, hw, dilation, float(eps), _p(ws), ws.numel(), _stream()), "frl_tcn_hot_bwd")
         g["dx"] = dx
