@@ -5,6 +5,5 @@ cd "$(dirname "$0")"
 CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I ../../vq-vae_amd/csrc -I ../../include"
 $CC -o tcn_bwd_v2.bin tcn_bwd_stamps.hip
 $CC -DTH_STAMPS -o tcn_bwd_v2_stamps.bin tcn_bwd_stamps.hip
-$CC -DTH_BWD_V1 -o tcn_bwd_v1.bin tcn_bwd_stamps.hip
 $CC -o vq_stamps.bin vq_stamps.hip
 $CC -o c3_stamps.bin c3_stamps.hip

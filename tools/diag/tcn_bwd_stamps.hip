@@ -1,6 +1,6 @@
 // Diagnostic harness (not part of the product library): runs the hot TCN backward kernel with s_memtime stamps at its phase
 // boundaries and prints the median cycles per phase.  Build: tools/diag/build.sh ; run on the GPU box: tools/diag/tcn_bwd_stamps
-// build variants (tools/diag/build.sh): -DTH_STAMPS -DTH_BWD_V1 (stamped 4-wave kernel), -DTH_BWD_V1 (4-wave), default (8-wave)
+// build variants (tools/diag/build.sh): default (timing only), -DTH_STAMPS (phase stamps)
 #include "../../vq-vae_amd/csrc/tcn_hot.hip"
 #include "../../vq-vae_amd/csrc/frl_host.hip"
 #include <vector>
@@ -54,7 +54,6 @@ int main(int argc, char** argv) {
 #ifndef TH_STAMPS
   return 0;
 #endif
-#ifndef TH_BWD_V1
   {
     std::vector<unsigned long long> h2((size_t)256 * 96);
     CK(hipMemcpy(h2.data(), dbg, h2.size() * 8, hipMemcpyDeviceToHost));
@@ -69,23 +68,6 @@ int main(int argc, char** argv) {
       printf("phase %2d %-36s %8.0f cycles / tile (mean over waves)\n", ph, nm[ph], sum);
     }
     printf("total %.0f cycles / tile\n", tot);
-    return 0;
-  }
-#endif
-  std::vector<unsigned long long> h(ndbg);
-  CK(hipMemcpy(h.data(), dbg, ndbg * 8, hipMemcpyDeviceToHost));
-  const char* names[8] = {"load+conv+stats", "P1 t-loop", "dconv+dx(convT)+store", "wait barrier1", "P2 gate wgrad", "wait barrier2+P3 publish+barrier3",
-                          "P4 conv wgrad", "barrier4 + loop"};
-  for (int ph = 0; ph < 8; ++ph) {
-    std::vector<double> d;
-    for (size_t w = 0; w < 1024; ++w)
-      for (int it = 1; it < 15; ++it) {
-        const unsigned long long* p = &h[(w * 16 + it) * 8];
-        const unsigned long long a = p[ph], b = ph < 7 ? p[ph + 1] : h[(w * 16 + it + 1) * 8];
-        if (a && b && b > a) d.push_back((double)(b - a));
-      }
-    std::sort(d.begin(), d.end());
-    if (!d.empty()) printf("phase %d %-36s median %8.0f  p10 %8.0f  p90 %8.0f cycles (n=%zu)\n", ph, names[ph], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10], d.size());
   }
   return 0;
 }

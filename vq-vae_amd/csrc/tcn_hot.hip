@@ -8,26 +8,19 @@
 // exact two-pass in-lane reduction over those accumulators, and the gate GEMM / sigmoid / blend read them in place.
 //
 //   forward : y = g * relu(n) + (1 - g) * x,  n = GN(conv(x) + b),  g = sigmoid(Wg n + bg)          (x read, y written: 2 x 128 B / (px,t))
-//   backward: ONE launch -> dx + every parameter gradient.  Per 64-pixel workgroup tile:
-//     P1 (per wave, no barrier)  recompute conv/GN/gate, dgpre, dres, dn, GroupNorm backward -> dconv, dx = conv^T(dconv) + dres
-//                                (stored), publish bf16 images of n[t], dgpre[t] for all t into LDS
-//     P2 gate weight gradient    dWg += dgpre^T n   (contraction over the 64 pixels x 5 t; operands via ds_read_b64_tr_b16)
-//     P3 publish dconv[t], x[t]  into the same LDS tiles
-//     P4 conv weight gradient    dW_k += dconv[t]^T x[t + (k-1) d]
-//   Four barriers per tile; wave w owns rows [16w, 16w+16) of the four 64x64 gradient matrices in registers for the whole
-//   kernel; per-workgroup float32 slabs are summed in a fixed order afterwards (bit-reproducible, no float atomics).
+//   backward: ONE launch -> dx + every parameter gradient (tcn_hot_bwd2_kernel, 8 waves per workgroup with a channel-half split;
+//             the phase structure is described above the kernel).  Wave (q, h) owns rows [16q, 16q+16) x columns [32h, 32h+32) of the
+//             four 64x64 gradient matrices in registers for the whole kernel; per-workgroup float32 slabs are summed in a fixed order
+//             afterwards (bit-reproducible, no float atomics).
 #include "tcn_common.hpp"
 #include "frl_host.hpp"
 #include "frl_reduce.hpp"
 
 #define TH_T 5
 // Diagnostic build only (tools/diag/tcn_bwd_stamps.hip defines TH_STAMPS): s_memtime stamps at the phase boundaries of the
-// backward kernel, written to a buffer nothing else reads.  The product library never defines it.
+// backward kernel, accumulated in LDS and written to a buffer nothing else reads.  The product library never defines it.
 #ifdef TH_STAMPS
 __device__ unsigned long long* th_dbg;
-#define TH_STAMP(i) do { if (lane == 0 && wt_iter < 16) th_dbg[(((size_t)blockIdx.x * 4 + wave) * 16 + wt_iter) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define TH_STAMP(i) do { } while (0)
 #endif
 #define TH_PITCH 72       // bf16 elements per pixel row in LDS tiles (64 + 8: conflict-free 16-byte writes and tr16 reads)
 
@@ -218,271 +211,6 @@ __device__ __forceinline__ void th_put(bf16* tile, int prow, int kc, const Tile2
 // slab layout per workgroup (floats): [3][64][64] conv taps | [64][64] gate | [64] dbc | [64] dbg | [64] dgamma | [64] dbeta
 #define TH_SLAB (4 * 64 * 64 + 4 * 64)
 #define TH_TILE (64 * TH_PITCH)
-
-template <int DIL>
-__global__ __launch_bounds__(256) void tcn_hot_bwd_kernel(const bf16* __restrict__ X, const bf16* __restrict__ DY,
-                                                          const frag8* __restrict__ Wpk, const float* __restrict__ bc,
-                                                          const float* __restrict__ gn_w, const float* __restrict__ gn_b,
-                                                          const float* __restrict__ bg, bf16* __restrict__ DX, float* __restrict__ slab,
-                                                          int64_t npix, int HW, float eps) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  frag8* wl_conv = reinterpret_cast<frag8*>(smem);               // [3][4][2][64]
-  frag8* wl_gate = wl_conv + 24 * 64;                            // [4][2][64]
-  frag8* wl_gateT = wl_gate + 8 * 64;                            // [4][2][64]
-  frag8* wl_convT = wl_gateT + 8 * 64;                           // [3][4][2][64]
-  float* tab = reinterpret_cast<float*>(wl_convT + 24 * 64);     // conv bias | gamma | beta | -log2e * gate bias
-  float* gacc_lds = tab + 4 * 64;                                // [4 waves][2][64]
-  bf16* bufA = reinterpret_cast<bf16*>(gacc_lds + 4 * 2 * 64);   // [T][64 px][PITCH]  dgpre[t], later dconv[t]
-  bf16* bufB = bufA + TH_T * TH_TILE;                            // [T][64 px][PITCH]  n[t],     later x[t]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int px = lane & 15, kc = lane >> 4, r16 = px;
-  const int prow = wave * 16 + px;
-
-  copy_frags_lds<bf16>(wl_conv, Wpk, 64 * 64, tid, 256);
-  if (tid < 64) {
-    tab[tid] = bc[tid];
-    tab[64 + tid] = gn_w[tid];
-    tab[128 + tid] = gn_b[tid];
-    tab[192 + tid] = -1.44269504088896f * bg[tid];
-  }
-  __syncthreads();
-  const f32x4* tcb = reinterpret_cast<const f32x4*>(tab + 16 * kc);
-  const float* tgw = tab + 64 + 16 * kc;
-  const float* tgb = tab + 128 + 16 * kc;
-  const float* tnbg = tab + 192 + 16 * kc;
-
-  f32x4 accC[3][4], accG[4], accCb = {0.f, 0.f, 0.f, 0.f}, accGb = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) accC[k][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) accG[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float dgam[16], dbet[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) { dgam[j] = 0.f; dbet[j] = 0.f; }
-  const frag8 ones = (r16 == 0) ? frag8{(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f}
-                                : frag8{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-
-  const int64_t nwt = (npix + 63) >> 6;
-  int wt_iter = 0;
-  for (int64_t wt = blockIdx.x; wt < nwt; wt += gridDim.x, ++wt_iter) {
-    TH_STAMP(0);
-    int64_t pidx = wt * 64 + prow;
-    const bool valid = pidx < npix;
-    if (!valid) pidx = npix - 1;
-    const int64_t b = pidx / HW, hw = pidx % HW;
-    const int64_t row0 = b * TH_T * HW + hw;
-    const bf16* xp = X + row0 * 64 + 16 * kc;
-    const bf16* dyp = DY + row0 * 64 + 16 * kc;
-    Tile2 x[TH_T];
-#pragma unroll
-    for (int t = 0; t < TH_T; ++t) x[t] = th_load(xp + (int64_t)t * HW * 64);
-    Tile2 dyc = th_load(dyp);                                      // dy[t] is fetched one time step ahead of its use
-    // ---------------- P1: per-pixel backward ----------------
-    f32x4 acc[TH_T][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const f32x4 cb = tcb[m];
-#pragma unroll
-      for (int t = 0; t < TH_T; ++t) acc[t][m] = cb;
-    }
-    th_conv<DIL>(acc, x, wl_conv, lane);
-    float mean[2], rstd[2];
-    th_stats(acc, eps, mean, rstd);
-    TH_STAMP(1);
-    const float nm[2] = {-mean[0] * rstd[0], -mean[1] * rstd[1]};
-    float S1[2] = {0.f, 0.f}, S2[2] = {0.f, 0.f};
-    Tile2 dxh[TH_T];
-    bf16* dxp = DX + row0 * 64 + 16 * kc;                          // dres[t] is parked in dx (L2) until the conv^T pass
-#pragma unroll
-    for (int t = 0; t < TH_T; ++t) {
-      __builtin_amdgcn_sched_barrier(0);
-      Tile2 dyt = dyc;
-      if (t + 1 < TH_T) dyc = th_load(dyp + (int64_t)(t + 1) * HW * 64);
-      if (!valid) { dyt.f[0] = frag8{}; dyt.f[1] = frag8{}; }     // clamped duplicate pixel: contributes nothing
-      float xh[16], n[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        xh[j] = fmaf(acc[t][j >> 2][j & 3], rstd[j >> 3], nm[j >> 3]);
-        acc[t][j >> 2][j & 3] = xh[j];                            // keep xhat for the GroupNorm backward
-        n[j] = fmaf(xh[j], tgw[j], tgb[j]);
-      }
-      const Tile2 nt = th_pack(n);
-      th_put(bufB + t * TH_TILE, prow, kc, nt);
-      f32x4 gacc[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        gacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 2; ++s) gacc[m] = mfma16(wl_gate[(m * 2 + s) * 64 + lane], nt.f[s], gacc[m]);
-      }
-      float dgp[16], drv[16];
-      f32x4 bacc[4];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float dyv = th_elem(dyt, j);
-        const float g = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(gacc[j >> 2][j & 3], -1.44269504088896f, tnbg[j])));
-        const float o = fmaxf(n[j], 0.f);
-        const float res = th_elem(x[t], j);
-        const float dyg = dyv * g;
-        drv[j] = dyv - dyg;                                        // dy (1 - g)
-        dgp[j] = (o - res) * (dyg - dyg * g);                      // dy (o - res) g (1 - g)
-        bacc[j >> 2][j & 3] = n[j] > 0.f ? dyg : 0.f;              // relu path of dn; Wg^T dgpre is accumulated on top
-      }
-      const Tile2 gt = th_pack(dgp);
-      th_put(bufA + t * TH_TILE, prow, kc, gt);
-      if (valid) th_store(dxp + (int64_t)t * HW * 64, th_pack(drv));   // (a clamped lane must not touch its alias)
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) bacc[m] = mfma16(wl_gateT[(m * 2 + s) * 64 + lane], gt.f[s], bacc[m]);
-      float d[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float dnv = bacc[j >> 2][j & 3];
-        dgam[j] = fmaf(dnv, xh[j], dgam[j]);
-        dbet[j] += dnv;
-        d[j] = dnv * tgw[j];
-        S1[j >> 3] += d[j];
-        S2[j >> 3] = fmaf(d[j], xh[j], S2[j >> 3]);
-      }
-      dxh[t] = th_pack(d);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    TH_STAMP(2);
-    Tile2 dct[TH_T];
-    {
-      const float m1[2] = {S1[0] * (1.f / 40.f), S1[1] * (1.f / 40.f)};
-      const float m2[2] = {S2[0] * (1.f / 40.f), S2[1] * (1.f / 40.f)};
-#pragma unroll
-      for (int t = 0; t < TH_T; ++t) {
-        float dc[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          dc[j] = rstd[j >> 3] * (th_elem(dxh[t], j) - m1[j >> 3] - acc[t][j >> 2][j & 3] * m2[j >> 3]);
-        dct[t] = th_pack(dc);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // dx[t'] = sum_k W_k^T dconv[t' - (k-1) d] + dres[t']   (accumulators initialised with dres)
-    {
-      f32x4 dxa[TH_T][4];
-#pragma unroll
-      for (int t = 0; t < TH_T; ++t) {
-        const Tile2 drt = th_load(dxp + (int64_t)t * HW * 64);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-          dxa[t][m] = f32x4{th_elem(drt, 4 * m), th_elem(drt, 4 * m + 1), th_elem(drt, 4 * m + 2), th_elem(drt, 4 * m + 3)};
-      }
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const frag8 wf = wl_convT[((k * 4 + m) * 2 + s) * 64 + lane];
-#pragma unroll
-            for (int tp = 0; tp < TH_T; ++tp)
-              if (th_valid<DIL>(tp, 2 - k)) dxa[tp][m] = mfma16(wf, dct[tp - (k - 1) * DIL].f[s], dxa[tp][m]);
-          }
-      if (valid) {
-#pragma unroll
-        for (int t = 0; t < TH_T; ++t) {
-          float y[16];
-#pragma unroll
-          for (int j = 0; j < 16; ++j) y[j] = dxa[t][j >> 2][j & 3];
-          th_store(dxp + (int64_t)t * HW * 64, th_pack(y));
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    TH_STAMP(3);
-    __syncthreads();                                               // n[t], dgpre[t] of the whole workgroup are resident
-    TH_STAMP(4);
-    // ---------------- P2: gate weight gradient ----------------
-#pragma unroll
-    for (int t = 0; t < TH_T; ++t) {
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int pix0 = ks * 32 + 8 * kc;
-        const frag8 af = th_tr(bufA + t * TH_TILE, pix0, wave * 16, r16);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) accG[i] = mfma16(af, th_tr(bufB + t * TH_TILE, pix0, i * 16, r16), accG[i]);
-        accGb = mfma16(af, ones, accGb);
-      }
-    }
-    TH_STAMP(5);
-    __syncthreads();
-    // ---------------- P3: publish dconv[t], x[t] ----------------
-#pragma unroll
-    for (int t = 0; t < TH_T; ++t) {
-      th_put(bufA + t * TH_TILE, prow, kc, dct[t]);
-      th_put(bufB + t * TH_TILE, prow, kc, x[t]);
-    }
-    __syncthreads();
-    TH_STAMP(6);
-    // ---------------- P4: conv weight gradients  dW_k += dconv[tp - (k-1) d]^T x[tp] ----------------
-#pragma unroll
-    for (int tp = 0; tp < TH_T; ++tp) {
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int pix0 = ks * 32 + 8 * kc;
-        frag8 bf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bf[i] = th_tr(bufB + tp * TH_TILE, pix0, i * 16, r16);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          if (!th_valid<DIL>(tp, 2 - k)) continue;
-          const frag8 af = th_tr(bufA + (tp - (k - 1) * DIL) * TH_TILE, pix0, wave * 16, r16);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) accC[k][i] = mfma16(af, bf[i], accC[k][i]);
-          if (k == 1) accCb = mfma16(af, ones, accCb);
-        }
-      }
-    }
-    TH_STAMP(7);
-    __syncthreads();                                               // tiles are rewritten by the next workgroup tile
-  }
-  // ---------------- d gamma / d beta: reduce over the 16 pixel lanes, then over waves ----------------
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) { dgam[j] += __shfl_xor(dgam[j], off, 64); dbet[j] += __shfl_xor(dbet[j], off, 64); }
-  }
-  if (px == 0) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { gacc_lds[(wave * 2 + 0) * 64 + 16 * kc + j] = dgam[j]; gacc_lds[(wave * 2 + 1) * 64 + 16 * kc + j] = dbet[j]; }
-  }
-  // ---------------- write this workgroup's slab ----------------
-  float* my = slab + (int64_t)blockIdx.x * TH_SLAB;
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) my[(k * 64 + wave * 16 + kc * 4 + r) * 64 + i * 16 + r16] = accC[k][i][r];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) my[(3 * 64 + wave * 16 + kc * 4 + r) * 64 + i * 16 + r16] = accG[i][r];
-  if (r16 == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      my[4 * 64 * 64 + wave * 16 + kc * 4 + r] = accCb[r];
-      my[4 * 64 * 64 + 64 + wave * 16 + kc * 4 + r] = accGb[r];
-    }
-  }
-  __syncthreads();
-  for (int i = tid; i < 2 * 64; i += 256) {
-    const int which = i >> 6, c = i & 63;
-    float s = 0.f;
-    for (int w = 0; w < 4; ++w) s += gacc_lds[(w * 2 + which) * 64 + c];
-    my[4 * 64 * 64 + 128 + i] = s;
-  }
-}
 
 // =============================================================================================================
 // backward, 8 waves per workgroup (two per SIMD): wave (q, h) owns the 16 pixels of quarter q and the channel half h of every
@@ -918,12 +646,6 @@ static int th_launch_fwd(const void* x, const void* mask, const frag8* pk, const
 template <int DIL>
 static int th_launch_bwd(const void* x, const void* mask, const void* dy, const frag8* pk, const float* bc, const float* gw, const float* gb,
                          const float* bg, void* dx, float* slab, unsigned grid, int64_t npix, int HW, float eps, hipStream_t st) {
-#ifdef TH_BWD_V1
-  if (mask != nullptr) return frl_fail(-2, "tcn_hot_bwd (4-wave diagnostic build): dropout mask unsupported");
-  auto kern = tcn_hot_bwd_kernel<DIL>;
-  FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TH_BWD_LDS));
-  FRL_LAUNCH(kern, dim3(grid), dim3(256), TH_BWD_LDS, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx, slab, npix, HW, eps);
-#else
   if (mask != nullptr) {
     auto kern = tcn_hot_bwd2_kernel<DIL, true>;
     FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TH_BWD_LDS));
@@ -935,7 +657,6 @@ static int th_launch_bwd(const void* x, const void* mask, const void* dy, const 
     FRL_LAUNCH(kern, dim3(grid), dim3(512), TH_BWD_LDS, st, (const bf16*)x, (const bf16*)nullptr, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx,
                slab, npix, HW, eps);
   }
-#endif
   return 0;
 }
 
