@@ -64,7 +64,7 @@ def cpu_baseline(args):
     import frl_oracle as O
     cores = min(os.cpu_count() or 1, 16)      # the box's CPU share for one GPU; more threads only thrash on these small ops
     torch.set_num_threads(cores)
-    bs = 8
+    bs = 16                                    # bounded sample: ~10 s of host work (1 warm-up + 8 timed steps of 16 tiles)
     g = torch.Generator().manual_seed(0)
     from frl_hip.models import VQVAE
     m = VQVAE(in_features=args.features, codebook_size=args.codebook, emb_dim=args.emb_dim, type_encoder_dropout=0.0,
@@ -75,7 +75,7 @@ def cpu_baseline(args):
     tiles = [torch.randn(bs, args.time, args.size, args.size, args.features, generator=g) for _ in range(2)]
     tr.step(tiles[0])
     t0 = time.perf_counter()
-    n = 3
+    n = 8
     for i in range(n):
         tr.step(tiles[i % 2])
     dt = time.perf_counter() - t0

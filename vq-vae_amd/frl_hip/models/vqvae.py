@@ -77,6 +77,15 @@ class VQVAE(RepresentationModel):
                 self.quant_phase = VectorQuantizer(phase_codebook_size, self.z_phase_dim, beta, quantizer, ema_decay, ema_eps)
         self.codebook_manager = None
         self.fused_decoder = True
+        # The phase path is conditioned on stopgrad(z_type): forward AND backward of the two branches are independent, so the phase
+        # branch runs on a side HIP stream next to VQ + type decoder (forward) and next to the whole type-path backward.
+        self.concurrent_phase = True
+        self._side_stream = None
+
+    def phase_stream(self, device):
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=device)
+        return self._side_stream
 
     def attach_codebook_manager(self, manager) -> None:
         """scripts/train_vqvae.py:197-198: the manager tracks usage / dead codes from `quant.last_counts`."""
@@ -94,6 +103,26 @@ class VQVAE(RepresentationModel):
         xhat = dec(z)
         return Fh.mse_loss(xhat, target, mask), xhat
 
+    def _phase_branch(self, tile, z_type_detached, mask, return_recon) -> Dict[str, torch.Tensor]:
+        """Dense phase path -> (optional phase codebook) -> phase decoder + masked L2; returns its outputs and `loss_terms`."""
+        b, t, hh, ww, f = tile.shape
+        out: Dict[str, torch.Tensor] = {}
+        z_phase = self.forward_phase_nhwc(tile, z_type_detached)            # [B,T,H,W,zp]
+        zp_in = z_phase
+        terms = None
+        if hasattr(self, "quant_phase"):
+            zpq, pvq, pperp, pidx = self.quant_phase(z_phase.reshape(-1, z_phase.shape[-1]))
+            zp_in = zpq.reshape(z_phase.shape)
+            terms = self.lambda_vq * pvq
+            out.update(idx_phase=pidx, vq_loss_phase=pvq, perplexity_phase=pperp)
+        pmask = None if mask is None else mask.unsqueeze(1).expand(b, t, hh, ww).contiguous()
+        l_phase, xhat_phase = self._decode_loss(self.decoder_phase, zp_in, tile, pmask, return_recon)
+        terms = self.lambda_recon * l_phase if terms is None else terms + self.lambda_recon * l_phase
+        out.update(z_phase=z_phase, l_phase=l_phase, loss_terms=terms)
+        if xhat_phase is not None:
+            out["xhat_phase"] = xhat_phase
+        return out
+
     def forward_tiles(self, tile: torch.Tensor, mask: Optional[torch.Tensor] = None,
                       return_recon: bool = False) -> Dict[str, torch.Tensor]:
         """tile [B,T,H,W,F] (any float dtype, GPU) -> dict(loss, l_type, l_phase, vq_loss, perplexity, idx, ...).
@@ -104,6 +133,17 @@ class VQVAE(RepresentationModel):
         with torch.no_grad():
             x_type = ops.mean_time(tile)                                   # [B,H,W,F]
         z_type, gate = self.forward_nhwc(x_type, return_gate=True)          # [B,H,W,d]
+        side = ph = None
+        if self.phase and self.concurrent_phase and tile.is_cuda:
+            main, side = torch.cuda.current_stream(), self.phase_stream(tile.device)
+            side.wait_stream(main)
+            zt = z_type.detach()
+            zt.record_stream(side)
+            tile.record_stream(side)
+            if mask is not None:
+                mask.record_stream(side)
+            with torch.cuda.stream(side):
+                ph = self._phase_branch(tile, zt, mask, return_recon)
         d = z_type.shape[-1]
         zq, vq_loss, perp, idx = self.quant(z_type.reshape(-1, d))
         l_type, xhat_type = self._decode_loss(self.decoder_type, zq.reshape(b, hh, ww, d), x_type, mask, return_recon)
@@ -112,19 +152,15 @@ class VQVAE(RepresentationModel):
             out["xhat_type"] = xhat_type
         loss = self.lambda_recon * l_type + self.lambda_vq * vq_loss
         if self.phase:
-            z_phase = self.forward_phase_nhwc(tile, z_type.detach())       # [B,T,H,W,zp]
-            zp_in = z_phase
-            if hasattr(self, "quant_phase"):
-                zpq, pvq, pperp, pidx = self.quant_phase(z_phase.reshape(-1, z_phase.shape[-1]))
-                zp_in = zpq.reshape(z_phase.shape)
-                loss = loss + self.lambda_vq * pvq
-                out.update(idx_phase=pidx, vq_loss_phase=pvq, perplexity_phase=pperp)
-            pmask = None if mask is None else mask.unsqueeze(1).expand(b, t, hh, ww).contiguous()
-            l_phase, xhat_phase = self._decode_loss(self.decoder_phase, zp_in, tile, pmask, return_recon)
-            loss = loss + self.lambda_recon * l_phase
-            out.update(z_phase=z_phase, l_phase=l_phase)
-            if xhat_phase is not None:
-                out["xhat_phase"] = xhat_phase
+            if side is not None:
+                main.wait_stream(side)
+                for v in ph.values():
+                    if torch.is_tensor(v):
+                        v.record_stream(main)
+            else:
+                ph = self._phase_branch(tile, z_type.detach(), mask, return_recon)
+            loss = loss + ph.pop("loss_terms")
+            out.update(ph)
         out["loss"] = loss
         if self.codebook_manager is not None and hasattr(self.codebook_manager, "update"):
             self.codebook_manager.update(self.quant.last_counts)

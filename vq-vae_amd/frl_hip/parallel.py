@@ -42,6 +42,7 @@ class BucketedGradAllReduce:
                 self._index[id(p)] = bi
         self.comm_stream = torch.cuda.Stream() if (self.buckets and self.buckets[0][0].is_cuda) else None
         self._hooks = []
+        self.extra_streams = []                             # streams besides the hook's own that produce gradients of a bucket
         self.flag_src = None                                # float32 [1] tensor (1 = this rank saw a non-finite loss), set per step
         self._tables: Dict[int, tuple] = {}                 # bucket -> (gradient pointer key, device desc table, device chunk table)
         self.on_gpu = bool(self.buckets) and self.buckets[0][0].is_cuda
@@ -71,6 +72,8 @@ class BucketedGradAllReduce:
         bucket, flat = self.buckets[bi], self._flat[bi]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            for st in self.extra_streams:                  # e.g. the phase-branch stream of the model
+                self.comm_stream.wait_stream(st)
             ctx = torch.cuda.stream(self.comm_stream)
         else:
             ctx = _Null()

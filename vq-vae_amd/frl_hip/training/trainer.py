@@ -42,6 +42,8 @@ class VQVAETrainer:
         self.epoch = 0
         self.skipped = 0
         self.reducer = BucketedGradAllReduce(named) if (dist.is_available() and dist.is_initialized()) else None
+        if self.reducer is not None and on_gpu and getattr(model, "concurrent_phase", False) and hasattr(model, "phase_stream"):
+            self.reducer.extra_streams.append(model.phase_stream(rest[0].device))
 
     @property
     def n_skipped(self) -> int:
