@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-finite-check", action="store_true")
+    ap.add_argument("--serial-streams", action="store_true",
+                    help="run the phase branch on the main stream (per-kernel profiling: no overlap between the two branches)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; nccl == RCCL (the measured configuration), gloo only to rehearse the N>1 control flow")
     ap.add_argument("--torch-optimizer", action="store_true", help="A/B: clip_grad_norm_ + torch.optim.AdamW instead of the two HIP launches")
@@ -111,6 +113,7 @@ def main():
                   type_encoder_dropout=0.0, phase_tcn_dropout=0.0, compute_dtype=dtype).to(dev)
     with torch.no_grad():   # well-separated codebook so that all codes are used
         model.quant.codebook.copy_(torch.randn(args.codebook, args.emb_dim, generator=torch.Generator().manual_seed(7)))
+    model.concurrent_phase = not args.serial_streams
     trainer = VQVAETrainer(model, lr=1e-4, total_steps=10000, check_finite=not args.no_finite_check, fused_optimizer=not args.torch_optimizer)
     stream = SyntheticTileStream(args.batch, args.time, args.size, args.features, device=dev, dtype=dtype, seed=1234 + rank)
 
@@ -133,6 +136,7 @@ def main():
     ksum, ksteps = {}, 0
     if not args.no_kernel_timing:                     # separate instrumented steps: HIP events around every C-ABI call (rank 0)
         ksteps = max(2, min(5, args.steps))           # EVERY rank runs them: a step contains collectives
+        model.concurrent_phase = False                # per-kernel spans are only meaningful without the two branches overlapping
         if timing:
             ops.set_timing(True)
         for _ in range(ksteps):

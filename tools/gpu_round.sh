@@ -10,8 +10,8 @@ tail -2 $out/tests.log
 python bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err || { tail -20 $out/bench.err; exit 1; }
 cat $out/bench.json
 [ -n "$quick" ] && exit 0
-rocprofv3 --kernel-trace --stats -d $out/prof -o run -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/prof.log 2>&1 || { tail -20 $out/prof.log; exit 1; }
-rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/pmc_fetch.log 2>&1 || { tail -20 $out/pmc_fetch.log; exit 1; }
-rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/pmc_write.log 2>&1 || { tail -20 $out/pmc_write.log; exit 1; }
+rocprofv3 --kernel-trace --stats -d $out/prof -o run -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --serial-streams > $out/prof.log 2>&1 || { tail -20 $out/prof.log; exit 1; }
+rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --serial-streams > $out/pmc_fetch.log 2>&1 || { tail -20 $out/pmc_fetch.log; exit 1; }
+rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --serial-streams > $out/pmc_write.log 2>&1 || { tail -20 $out/pmc_write.log; exit 1; }
 find $out -name '*kernel_trace.csv' -size +20M -delete
 echo round-ok

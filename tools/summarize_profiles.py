@@ -37,7 +37,7 @@ def main():
     src, name = sys.argv[1], sys.argv[2]
     os.makedirs("profiles", exist_ok=True)
     stats, tot = kernel_stats(os.path.join(src, "prof", "run_results.db"))
-    cmd = "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+    cmd = "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --serial-streams"
     with open(f"profiles/{name}_kernel_stats.csv", "w") as f:
         f.write("name,calls,total_ms,avg_us,min_us,max_us,pct,vgpr,agpr,sgpr,lds,scratch,grid,wg\n")
         for s in stats:
@@ -45,7 +45,7 @@ def main():
                                                                                 s["max_us"], s["pct"], s["vgpr"], s["agpr"], s["sgpr"], s["lds"],
                                                                                 s["scratch"], s["grid"], s["wg"]))
     with open(f"profiles/{name}_kernel_stats.md", "w") as f:
-        f.write(f"# {cmd}  (MI355X, {name})\n\n30 train steps in the process (5 warm-up + 20 timed + 5 event-instrumented); GPU kernel time total "
+        f.write(f"# {cmd}  (MI355X, {name})\n\n30 train steps in the process (5 warm-up + 20 timed + 5 event-instrumented), phase branch on the main stream so that kernel durations are not stretched by the overlap of the two branches; GPU kernel time total "
                 f"{tot:.1f} ms = {tot / 30:.3f} ms/step.\n\n| kernel | calls | total ms | avg us | % | vgpr | lds B | scratch B |\n|---|---|---|---|---|---|---|---|\n")
         for s in stats[:60]:
             f.write("| `%s` | %d | %.2f | %.1f | %.2f | %d | %d | %d |\n" % (s["name"][:90], s["calls"], s["total_ms"], s["avg_us"], s["pct"],
@@ -59,7 +59,7 @@ def main():
         ks[k] = {"launches": fe.get(k, wr.get(k))[0], "FETCH_SIZE_KB_avg": round(f_kb, 2), "WRITE_SIZE_KB_avg": round(w_kb, 2),
                  "hbm_bytes_per_launch": int((2.0 * f_kb + w_kb) * 1024)}
     json.dump({"note": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "
-                       "--no-kernel-timing`; values in KiB averaged over the launches of each kernel; hbm_bytes_per_launch = (2*FETCH_SIZE + "
+                       "--no-kernel-timing --serial-streams`; values in KiB averaged over the launches of each kernel; hbm_bytes_per_launch = (2*FETCH_SIZE + "
                        "WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 128-B requests of wide coalesced reads as 64 B, MI355X_MICROARCH.md)",
                "kernels": ks}, open(f"profiles/{name}_pmc.json", "w"), indent=1)
     if os.path.exists(os.path.join(src, "bench.json")):
