@@ -259,7 +259,8 @@ def roofline_for(name, ksum, args, model, n, s):
         first, second = (hbm, mfma) if hf >= mf else (mfma, hbm)
         base.update(first)
         base["other_ceiling"] = second
-        base["note"] = "limited by vector-ALU issue (about 36 VALU ops per element of the GroupNorm/gate chain), see DESIGN.md section 4"
+        base["note"] = ("latency / synchronisation bound today (SQ counters: 64% of wave time parked at s_waitcnt or barriers), vector-ALU "
+                        "floor ~140 us per launch (about 36 VALU ops per element of the GroupNorm/gate chain); see DESIGN.md section 4")
         return base
     if name == "vq_assign":
         b = n * (2 * d * s + 4) + args.codebook * d * 4
