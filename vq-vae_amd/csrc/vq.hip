@@ -351,8 +351,9 @@ __global__ __launch_bounds__(256) void vq_fixup_kernel(const T* __restrict__ Z, 
 
 // Same re-evaluation with the WHOLE (rounded) codebook resident in LDS ([K][d+1] f32, conflict-free column reads): one
 // coalesced fill per workgroup, then each wave walks its share of the flagged rows.  Used when K*(d+1)*4 fits in LDS.
+#define VQ_FIXL_WAVES 8      // waves per workgroup of the LDS-resident fix-up: one flagged row per wave at a time
 template <typename T>
-__global__ __launch_bounds__(256) void vq_fixup_lds_kernel(const T* __restrict__ Z, const float* __restrict__ E, int K, int d,
+__global__ __launch_bounds__(64 * VQ_FIXL_WAVES) void vq_fixup_lds_kernel(const T* __restrict__ Z, const float* __restrict__ E, int K, int d,
                                                            const int32_t* __restrict__ amb_list, VqHeader* __restrict__ hdr,
                                                            int32_t* __restrict__ idx_out, T* __restrict__ zq_out,
                                                            int32_t* __restrict__ counts_fix) {
@@ -361,20 +362,20 @@ __global__ __launch_bounds__(256) void vq_fixup_lds_kernel(const T* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pitch = d + 4, d4 = d >> 2;
   float* et = reinterpret_cast<float*>(smem);               // [K][pitch]
-  float* zrow = et + (size_t)K * pitch + (size_t)wave * d;  // [4][d]
+  float* zrow = et + (size_t)K * pitch + (size_t)wave * d;  // [VQ_FIXL_WAVES][d]
   const int namb = hdr->namb;
-  if ((int)blockIdx.x * 4 >= namb) return;                  // whole workgroup has no rows: skip the fill
+  if ((int)blockIdx.x * VQ_FIXL_WAVES >= namb) return;                  // whole workgroup has no rows: skip the fill
   {
     // coalesced fill with 8 independent 16-byte loads in flight per thread (one memory latency per 32 KB, not per 4 KB)
     const f32x4* E4 = reinterpret_cast<const f32x4*>(E);
     const int nv = K * d4;
-    for (int i0 = tid; i0 < nv; i0 += 256 * 8) {
+    for (int i0 = tid; i0 < nv; i0 += 64 * VQ_FIXL_WAVES * 8) {
       f32x4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256; v[u] = i < nv ? E4[i] : f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int u = 0; u < 8; ++u) { const int i = i0 + u * 64 * VQ_FIXL_WAVES; v[u] = i < nv ? E4[i] : f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int i = i0 + u * 256;
+        const int i = i0 + u * 64 * VQ_FIXL_WAVES;
         if (i < nv) {
           const int kk = i / d4, j = (i - kk * d4) * 4;
           *reinterpret_cast<f32x4*>(et + kk * pitch + j) = f32x4{to_f32(from_f32<T>(v[u][0])), to_f32(from_f32<T>(v[u][1])),
@@ -384,9 +385,9 @@ __global__ __launch_bounds__(256) void vq_fixup_lds_kernel(const T* __restrict__
     }
   }
   __syncthreads();
-  const int nwaves = gridDim.x * 4;
+  const int nwaves = gridDim.x * VQ_FIXL_WAVES;
   const float slack = 2.f * (float)(d + 8) * 1.1920929e-7f;
-  for (int it = blockIdx.x * 4 + wave; it < namb; it += nwaves) {
+  for (int it = blockIdx.x * VQ_FIXL_WAVES + wave; it < namb; it += nwaves) {
     const int64_t n = amb_list[it];
     __builtin_amdgcn_wave_barrier();
     for (int j = lane; j < d; j += 64) zrow[j] = to_f32(Z[n * (int64_t)d + j]);
@@ -838,11 +839,11 @@ static int launch_vq(const void* z, const float* E, int64_t N, int K, int d, int
     auto fk = vq_fixup_kernel<T>;
     if (fix_lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fix_lds));
   }
-  const size_t res_lds = ((size_t)K * (d + 4) + 4 * (size_t)d) * sizeof(float);
+  const size_t res_lds = ((size_t)K * (d + 4) + VQ_FIXL_WAVES * (size_t)d) * sizeof(float);
   if (res_lds <= 150 * 1024 && (d & 3) == 0) {
     auto fk = vq_fixup_lds_kernel<T>;
     if (res_lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds));
-    FRL_LAUNCH(fk, dim3(256), dim3(256), res_lds, st, (const T*)z, E, K, d, (const int32_t*)(ws + L.amb), hdr, idx, (T*)zq,
+    FRL_LAUNCH(fk, dim3(256), dim3(64 * VQ_FIXL_WAVES), res_lds, st, (const T*)z, E, K, d, (const int32_t*)(ws + L.amb), hdr, idx, (T*)zq,
                (int32_t*)(ws + L.counts_fix));
   } else {
     FRL_LAUNCH((vq_fixup_kernel<T>), dim3(VQ_FIX_WAVES / 4), dim3(256), fix_lds, st, (const T*)z, E, K, d,
