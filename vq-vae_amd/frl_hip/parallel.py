@@ -46,6 +46,7 @@ class BucketedGradAllReduce:
         self.flag_src = None                                # float32 [1] tensor (1 = this rank saw a non-finite loss), set per step
         self._tables: Dict[int, tuple] = {}                 # bucket -> (gradient pointer key, device desc table, device chunk table)
         self.on_gpu = bool(self.buckets) and self.buckets[0][0].is_cuda
+        self._train_stream = None
         if self.world > 1 or force_hooks:
             for bucket in self.buckets:
                 for p in bucket:
@@ -58,6 +59,9 @@ class BucketedGradAllReduce:
         return bool(self._hooks)
 
     def reset(self):
+        # called from the training thread at step boundaries: remember its stream -- a bucket's last gradient hook may fire on the
+        # model's side stream while other gradients of the same bucket were produced on this one
+        self._train_stream = torch.cuda.current_stream() if self.on_gpu else None
         self._pending = {bi: len(b) for bi, b in enumerate(self.buckets)}
         self._works = []
 
@@ -72,8 +76,9 @@ class BucketedGradAllReduce:
         bucket, flat = self.buckets[bi], self._flat[bi]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
-            for st in self.extra_streams:                  # e.g. the phase-branch stream of the model
-                self.comm_stream.wait_stream(st)
+            for st in [self._train_stream] + list(self.extra_streams):   # training stream + e.g. the model's phase-branch stream
+                if st is not None:
+                    self.comm_stream.wait_stream(st)
             ctx = torch.cuda.stream(self.comm_stream)
         else:
             ctx = _Null()
