@@ -304,3 +304,30 @@ def test_training_mode_dropout_runs_on_the_hip_path():
     assert torch.isfinite(out["loss"]).item() and tr.opt.applied_and_skipped == (1, 0)
     m.set_input_dropout_rate(0.2)                                              # per-epoch schedule hook of the reference trainer
     assert torch.isfinite(tr.step(tile)["loss"]).item()
+
+
+def test_two_rank_data_parallel_matches_single_process(golden_dir, tmp_path):
+    """SURVEY 8e acceptance on a small scale: two data-parallel ranks (each half of the batch) end up with the parameters of one
+    process trained on the whole batch.  The ranks share the GPU over gloo; everything else is the production route."""
+    import subprocess
+    import sys
+    from frl_hip.training.trainer import VQVAETrainer
+    fx_path = os.path.join(golden_dir, "vqvae_tiny_seed0.npz")
+    fx = _load(golden_dir, "vqvae_tiny_seed0")
+    if fx["tiles"].shape[1] % 2:
+        pytest.skip("fixture batch is odd")
+    out = str(tmp_path / "ddp_params.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29641", os.path.join(os.path.dirname(__file__), "ddp_gpu_worker.py"), out, fx_path],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(out)
+    m = _vqvae_from_fixture(fx)
+    tr = VQVAETrainer(m, lr=1e-3, total_steps=10)
+    tiles = torch.from_numpy(fx["tiles"]).float().to(DEV)
+    for step in range(2):
+        tr.step(tiles[step])
+    for n, p in m.named_parameters():
+        ref = p.detach().cpu().numpy()
+        assert np.abs(got[n] - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), n
