@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* frl_stream_t; /* hipStream_t */
 
-enum { FRL_F32 = 0, FRL_BF16 = 1 };
+enum { FRL_F32 = 0, FRL_BF16 = 1, FRL_F16 = 2 /* raw chunk-store rows of frl_normalize_tiles only */ };
 enum { FRL_ACT_NONE = 0, FRL_ACT_RELU = 1, FRL_ACT_SIGMOID = 2 };
 
 /* ---- library ------------------------------------------------------------------------------------------------- */
@@ -161,6 +161,32 @@ int frl_film_modulate_bwd(const void* dout, const void* h, const void* gamma, vo
                           int64_t B, int T, int64_t HW, int C, int dtype, frl_stream_t stream);
 int frl_mean_time_fwd(const void* tile, void* out, int64_t B, int T, int64_t HWC, int dtype, frl_stream_t stream);
 int frl_add(const void* a, const void* b, float scale_b, void* out, int64_t n, int dtype, frl_stream_t stream); /* out = a + scale_b*b */
+
+/* ---- tile ingest: chunk-store rows -> normalised training rows -------------------------------
+ * Replaces the per-channel numpy normalisation + masking of FeatureBuilder on the host
+ * (frl/data/loaders/builders/feature_builder.py:402-462 _apply_normalization, :487-548 _normalize_array, :709-737
+ * _apply_mask_to_data; presets of frl/data/normalization/normalization.py:116-254) by one pass on the device over the
+ * (time,y,x,feature) rows as stored (utils/data_stack.py:271-309).  Per feature f:
+ *     r = (x - sub) / div;  if (flags & 1) r = r * mul + add;  if (flags & 2) r = max(r, lo);  if (flags & 4) r = min(r, hi)
+ * (float32, that operation order, no fused multiply-add).  A row is valid iff valid[row] != 0 (when given) and all its F raw
+ * values are finite; invalid rows are written as zeros and mask_out[row] = 0.
+ * raw [rows][F] FRL_F32 | FRL_F16, table [F] device records, out [rows][F] FRL_F32 | FRL_BF16, F in {8,16,...,512}. */
+typedef struct FrlNormRec {
+  float sub, div, mul, add, lo, hi;
+  int flags; /* 1 rescale, 2 clamp below, 4 clamp above */
+  int pad;
+} FrlNormRec;
+int frl_normalize_tiles(const void* raw, int raw_dtype, const uint8_t* valid, const void* table, void* out, int out_dtype,
+                        uint8_t* mask_out, int64_t rows, int F, frl_stream_t stream);
+/* Same arithmetic with the tile cut done on the device: `chunk` is one whole stored chunk [T][CY][CX][F] (uploaded with ONE
+ * contiguous copy; batches are chunk-locked, utils/samplers.py:42-108), desc [ntiles] = int32 {y0, x0, h, w} per tile (device).
+ * Replaces the window read + zero padding of partial patches on the host (forest_dataset_v2.py:328-369): rows/columns beyond
+ * h/w are written as zeros with mask 0.  out [ntiles][T][tile][tile][F], mask_out [ntiles][T][tile][tile]. */
+int frl_normalize_chunk_tiles(const void* chunk, int raw_dtype, int T, int CY, int CX, int F, const int32_t* desc, int ntiles,
+                              int tile, const void* table, void* out, int out_dtype, uint8_t* mask_out, frl_stream_t stream);
+
+/* Host-side helper of the tile loader: multi-threaded memcpy of one stored chunk into the pinned upload buffer (no GPU work). */
+int frl_host_parallel_copy(void* dst, const void* src, size_t nbytes, int nthreads);
 
 /* ---- masked L2 reconstruction loss -----------------------------------------------------------------------------
  * frl/losses/reconstruction.py:95-139 (loss_type "l2", reduction "mean"); out = {mean, n_valid_elements}. */

@@ -469,3 +469,71 @@ class OracleTrainer:
         self.opt.step()
         self.step_idx += 1
         return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Tile ingest: per-channel normalisation + masking of raw (time, y, x, feature) rows.
+# **Parity unpinned by the reference**: its FeatureBuilder / Normalizer modules import `zarr` (absent in this image), so they
+# cannot be run here and the reference holds no fixture for them; this is a restatement from the source text, channel by
+# channel in the reference's own numpy form, against which the one-pass device kernel is compared bit for bit.
+# ---------------------------------------------------------------------------------------------------------------
+def normalize_channel_np(data: np.ndarray, preset: dict, stats: Optional[dict]) -> np.ndarray:
+    """One channel, float32 numpy.  Follows FeatureBuilder._normalize_array (frl/data/loaders/builders/feature_builder.py:487-548);
+    'minmax' follows MinMaxNormalizer (frl/data/normalization/normalization.py:172-201)."""
+    stats = stats or {}
+    kind = (preset or {}).get("type", "identity")
+    out = data.copy()
+    if kind == "zscore":                                            # feature_builder.py:504-509
+        mean, sd = stats.get("mean", 0.0), stats.get("sd", 1.0)
+        if sd < 1e-8:
+            sd = 1.0
+        out = (data - np.float32(mean)) / np.float32(sd)
+    elif kind == "robust_iqr":                                      # :511-518
+        q25, q50, q75 = stats.get("q25", 0.0), stats.get("q50", 0.0), stats.get("q75", 1.0)
+        iqr = q75 - q25
+        if iqr < 1e-8:
+            iqr = 1.0
+        out = (data - np.float32(q50)) / np.float32(iqr)
+    elif kind == "minmax":                                          # normalization.py:179-199
+        if preset.get("min") is not None and preset.get("max") is not None:
+            lo, hi = preset["min"], preset["max"]
+        else:
+            lo, hi = stats["min"], stats["max"]
+        rng = hi - lo
+        if not rng > 1e-8:
+            rng = 1.0
+        out = (data - np.float32(lo)) / np.float32(rng)
+    elif kind == "linear_rescale":                                  # feature_builder.py:520-531
+        in_min = preset.get("in_min") if preset.get("in_min") is not None else 0.0
+        in_max = preset.get("in_max") if preset.get("in_max") is not None else 1.0
+        out_min = preset.get("out_min") if preset.get("out_min") is not None else 0.0
+        out_max = preset.get("out_max") if preset.get("out_max") is not None else 1.0
+        in_range = in_max - in_min
+        if in_range < 1e-8:
+            in_range = 1.0
+        out_range = out_max - out_min
+        out = ((data - np.float32(in_min)) / np.float32(in_range)) * np.float32(out_range) + np.float32(out_min)
+    elif kind not in ("clamp", "none", "identity"):
+        raise ValueError(kind)
+    clamp = (preset or {}).get("clamp")
+    if clamp and clamp.get("enabled", False):                       # :539-546
+        cmin, cmax = clamp.get("min"), clamp.get("max")
+        if cmin is not None or cmax is not None:
+            out = np.clip(out, None if cmin is None else np.float32(cmin), None if cmax is None else np.float32(cmax))
+    return out.astype(np.float32)
+
+
+def normalize_tiles_np(raw: np.ndarray, valid: Optional[np.ndarray], presets: list, stats: list):
+    """raw [..., F] (float16 | float32; NaN = no data), valid [...] or None -> (normalised float32 [..., F], mask uint8 [...]).
+    Mask = given validity AND all features finite; invalid rows are zeroed AFTER normalisation
+    (FeatureBuilder.build_feature order, feature_builder.py:160-170; _apply_mask_to_data :709-737)."""
+    x = raw.astype(np.float32)
+    ok = np.isfinite(x).all(axis=-1)
+    if valid is not None:
+        ok &= valid.astype(bool)
+    out = np.empty_like(x)
+    with np.errstate(invalid="ignore", over="ignore"):
+        for c in range(x.shape[-1]):
+            out[..., c] = normalize_channel_np(x[..., c], presets[c], stats[c])
+    out = np.where(ok[..., None], out, np.float32(0.0))
+    return out, ok.astype(np.uint8)

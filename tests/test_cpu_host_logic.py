@@ -97,3 +97,84 @@ def test_checkpoint_round_trip_cpu(tmp_path):
     torch.save({"model_version": "3"}, p)
     with pytest.raises(RuntimeError):
         RepresentationModel.from_checkpoint(p, device="cpu")
+
+
+# ------------------------------------------------------------------------------------------------ tile ingest
+def test_chunk_batch_sampler_reproduces_reference_batches(golden_dir):
+    """tests/golden/sampler_batches.json was written by the reference's own ChunkBatchSampler (make_sampler_golden.py)."""
+    import json
+    from frl_hip.data.samplers import ChunkBatchSampler
+    sys_path_cases = json.load(open(os.path.join(golden_dir, "sampler_batches.json")))
+    for case in sys_path_cases:
+        rng = np.random.default_rng(case["layout_seed"])
+        chunks, nxt = [], 0
+        for n in case["chunk_sizes"]:
+            chunks.append(np.arange(nxt, nxt + n, dtype=np.int64))
+            nxt += n
+        if case.get("scramble"):
+            chunks = [rng.permutation(c) for c in chunks]
+        s = ChunkBatchSampler(chunks, case["batch_size"], drop_last=case["drop_last"], replacement_within_chunk=case["replacement"],
+                              seed=case["seed"])
+        np.random.seed(case["np_seed"])
+        got = [[list(map(int, b)) for b in s] for _ in range(case["epochs"])]
+        assert got == case["batches"], case["name"]
+        assert len(s) == case["length"]
+        if not case["replacement"]:                       # chunk-locked: a batch never mixes chunks
+            owner = {int(i): c for c, m in enumerate(chunks) for i in m}
+            assert all(len({owner[i] for i in b}) == 1 for ep in got for b in ep)
+            if not case["drop_last"]:
+                assert sorted(i for b in got[0] for i in b) == list(range(nxt))
+
+
+def test_shard_batches_gives_every_rank_the_same_number_of_steps():
+    from frl_hip.data.samplers import shard_batches
+    batches = [[i] for i in range(11)]
+    parts = [shard_batches(batches, r, 4) for r in range(4)]
+    assert [len(p) for p in parts] == [2, 2, 2, 2] and sorted(b[0] for p in parts for b in p) == list(range(8))
+
+
+def test_tile_store_and_chunk_dataset(tmp_path):
+    from frl_hip.data.tile_loader import ChunkTileDataset
+    from frl_hip.data.tile_store import TileStore, write_tile_store
+    rng = np.random.default_rng(0)
+    cube = rng.standard_normal((5, 70, 100, 8)).astype(np.float32)
+    cube[2, 5, 6, 3] = np.nan
+    write_tile_store(str(tmp_path / "s"), cube, (64, 64), dtype="float32")
+    st = TileStore(str(tmp_path / "s"))
+    assert st.grid == (2, 2) and st.num_chunks == 4 and st.chunk(1, 1).shape == (5, 64, 64, 8)
+    assert np.isnan(st.chunk(1, 1)[:, 6:, :, :]).all()                                     # edge chunks padded with no-data
+    ds = ChunkTileDataset(st, 32)
+    assert [len(c) for c in ds.xy_by_chunk] == [4, 4, 2, 2] and len(ds) == 12
+    seen = np.zeros((70, 100), dtype=int)
+    for i in range(len(ds)):
+        s = ds[i]
+        r, c, h, w = s["metadata"]["spatial_window"]
+        assert s["tile"].shape == (5, 32, 32, 8) and s["mask"].shape == (32, 32)
+        assert np.array_equal(s["tile"][:, :h, :w], cube[:, r:r + h, c:c + w], equal_nan=True)
+        assert s["mask"][:h, :w].all() and s["mask"].sum() == h * w                          # partial patches: zero padded, masked
+        assert np.all(s["tile"][:, h:] == 0) and np.all(s["tile"][:, :, w:] == 0)
+        seen[r:r + h, c:c + w] += 1
+    assert (seen == 1).all()                                                               # tiles partition the raster
+    with pytest.raises(IndexError):
+        ds[12]
+    with pytest.raises(ValueError):
+        ChunkTileDataset(st, 48)
+
+
+@pytest.mark.parametrize("features,dtype", [(8, np.float32), (64, np.float16)])
+def test_norm_records_equal_the_per_channel_oracle(features, dtype):
+    """The record table (what the device kernel consumes) evaluated in float32 numpy == the oracle's per-channel restatement."""
+    import frl_oracle as O
+    from frl_hip.data.normalization import NormPreset, norm_table
+    from tile_cases import apply_records_np, preset_mix, raw_rows
+    presets, stats = preset_mix(features)
+    table = norm_table([NormPreset.from_dict(p) for p in presets], stats)
+    assert table.dtype == np.uint8 and table.size == 32 * features
+    raw = raw_rows((3, 50, features), dtype, seed=features)
+    valid = (np.random.default_rng(1).random((3, 50)) > 0.1).astype(np.uint8)
+    ref, ref_mask = O.normalize_tiles_np(raw, valid, presets, stats)
+    got, got_mask = apply_records_np(raw, valid, table)
+    assert np.array_equal(got_mask, ref_mask) and 0 < ref_mask.sum() < ref_mask.size
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    with pytest.raises(ValueError):
+        NormPreset.from_dict({"type": "whiten"})

@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfrlhip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
 _lib = None
@@ -54,6 +54,9 @@ SIGNATURES = {
     "frl_gate_blend_bwd": (c_int, [P, P, P, P, F, P, P, L, I, P]),
     "frl_mean_time_fwd": (c_int, [P, P, L, I, L, I, P]),
     "frl_add": (c_int, [P, P, F, P, L, I, P]),
+    "frl_normalize_tiles": (c_int, [P, I, P, P, P, I, P, L, I, P]),
+    "frl_host_parallel_copy": (c_int, [P, P, S, I]),
+    "frl_normalize_chunk_tiles": (c_int, [P, I, I, I, I, I, P, I, I, P, P, I, P, P]),
     "frl_conv3x3_fwd": (c_int, [P, P, P, P, I, I, I, I, I, I, I, P, S, P]),
     "frl_conv3x3_bwd_data": (c_int, [P, P, I, P, P, I, I, I, I, I, I, P, S, P]),
     "frl_conv3x3_bwd_weight_workspace_bytes": (S, [I, I, I, I, I]),

@@ -115,7 +115,10 @@ class VQVAE(RepresentationModel):
             zp_in = zpq.reshape(z_phase.shape)
             terms = self.lambda_vq * pvq
             out.update(idx_phase=pidx, vq_loss_phase=pvq, perplexity_phase=pperp)
-        pmask = None if mask is None else mask.unsqueeze(1).expand(b, t, hh, ww).contiguous()
+        if mask is None or mask.dim() == 4:                                 # [B,T,H,W]: per-observation validity from the tile ingest
+            pmask = mask
+        else:
+            pmask = mask.unsqueeze(1).expand(b, t, hh, ww).contiguous()
         l_phase, xhat_phase = self._decode_loss(self.decoder_phase, zp_in, tile, pmask, return_recon)
         terms = self.lambda_recon * l_phase if terms is None else terms + self.lambda_recon * l_phase
         out.update(z_phase=z_phase, l_phase=l_phase, loss_terms=terms)
@@ -126,6 +129,8 @@ class VQVAE(RepresentationModel):
     def forward_tiles(self, tile: torch.Tensor, mask: Optional[torch.Tensor] = None,
                       return_recon: bool = False) -> Dict[str, torch.Tensor]:
         """tile [B,T,H,W,F] (any float dtype, GPU) -> dict(loss, l_type, l_phase, vq_loss, perplexity, idx, ...).
+        `mask` (1 = valid) is per pixel [B,H,W] or per observation [B,T,H,W] (as `TilePrefetcher` delivers it); with the latter the
+        type-path loss counts a pixel only if all its time steps are valid (its input is their mean).
         `xhat_type` / `xhat_phase` are present when return_recon=True or when the modular decoder path is taken."""
         self._require_gpu(tile)
         tile = self._rows(tile)
@@ -146,7 +151,8 @@ class VQVAE(RepresentationModel):
                 ph = self._phase_branch(tile, zt, mask, return_recon)
         d = z_type.shape[-1]
         zq, vq_loss, perp, idx = self.quant(z_type.reshape(-1, d))
-        l_type, xhat_type = self._decode_loss(self.decoder_type, zq.reshape(b, hh, ww, d), x_type, mask, return_recon)
+        tmask = mask.amin(dim=1) if (mask is not None and mask.dim() == 4) else mask
+        l_type, xhat_type = self._decode_loss(self.decoder_type, zq.reshape(b, hh, ww, d), x_type, tmask, return_recon)
         out = dict(z_type=z_type, gate=gate, idx=idx, vq_loss=vq_loss, perplexity=perp, l_type=l_type)
         if xhat_type is not None:
             out["xhat_type"] = xhat_type

@@ -310,6 +310,66 @@ def mean_time(tile: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_timed("normalize_tiles")
+def normalize_tiles(raw: torch.Tensor, table: torch.Tensor, valid: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.bfloat16,
+                    out: Optional[torch.Tensor] = None, mask_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Chunk-store rows [..., F] (float16 | float32, NaN = no data) -> normalised rows (bf16 | f32) + validity bytes [...].
+
+    `table` is the device image of the per-feature records (`data.normalization.norm_table`, 8 x 4 bytes per feature);
+    `valid` an optional uint8/bool tensor over the leading dims.  See include/frl_hip.h (frl_normalize_tiles)."""
+    if raw.dtype not in (torch.float16, torch.float32) or not raw.is_contiguous():
+        raise ValueError("normalize_tiles: raw rows must be contiguous float16 or float32")
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("normalize_tiles: output must be bfloat16 or float32")
+    f = raw.shape[-1]
+    rows = raw.numel() // f if f else 0
+    if table.dtype != torch.uint8 or table.numel() != 32 * f or table.device != raw.device:
+        raise ValueError("normalize_tiles: table must be the 32-byte-per-feature record image on the device of the rows")
+    if valid is not None:
+        if valid.dtype == torch.bool:
+            valid = valid.view(torch.uint8)
+        if valid.dtype != torch.uint8 or valid.numel() != rows or not valid.is_contiguous() or valid.device != raw.device:
+            raise ValueError("normalize_tiles: valid must be one contiguous byte per row")
+    if out is None:
+        out = torch.empty(raw.shape, dtype=out_dtype, device=raw.device)
+    if mask_out is None:
+        mask_out = torch.empty(raw.shape[:-1], dtype=torch.uint8, device=raw.device)
+    if out.shape != raw.shape or out.dtype != out_dtype or not out.is_contiguous() or mask_out.numel() != rows:
+        raise ValueError("normalize_tiles: output buffers do not match the rows")
+    check(_lib.load().frl_normalize_tiles(_p(raw), _lib.F16 if raw.dtype == torch.float16 else F32, _p(valid) if valid is not None else None,
+                                          _p(table), _p(out), _dt(out), _p(mask_out), rows, f, _stream()), "frl_normalize_tiles")
+    return out, mask_out
+
+
+@_timed("normalize_chunk_tiles")
+def normalize_chunk_tiles(chunk: torch.Tensor, desc: torch.Tensor, tile: int, table: torch.Tensor, out_dtype: torch.dtype = torch.bfloat16,
+                          out: Optional[torch.Tensor] = None, mask_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One stored chunk [T, CY, CX, F] (float16 | float32) + tile descriptors [B, 4] int32 {y0, x0, h, w} ->
+    normalised tiles [B, T, tile, tile, F] + validity bytes [B, T, tile, tile]; the tile cut and the zero padding of partial
+    patches happen on the device (frl_normalize_chunk_tiles)."""
+    if chunk.dim() != 4 or chunk.dtype not in (torch.float16, torch.float32) or not chunk.is_contiguous():
+        raise ValueError("normalize_chunk_tiles: chunk must be a contiguous float16/float32 [T, CY, CX, F] tensor")
+    t_, cy, cx, f = chunk.shape
+    if desc.dtype != torch.int32 or desc.dim() != 2 or desc.shape[1] != 4 or not desc.is_contiguous() or desc.device != chunk.device:
+        raise ValueError("normalize_chunk_tiles: desc must be a contiguous int32 [B, 4] tensor on the chunk's device")
+    if table.dtype != torch.uint8 or table.numel() != 32 * f or table.device != chunk.device:
+        raise ValueError("normalize_chunk_tiles: table must be the 32-byte-per-feature record image on the chunk's device")
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("normalize_chunk_tiles: output must be bfloat16 or float32")
+    b = desc.shape[0]
+    shape = (b, t_, tile, tile, f)
+    if out is None:
+        out = torch.empty(shape, dtype=out_dtype, device=chunk.device)
+    if mask_out is None:
+        mask_out = torch.empty(shape[:-1], dtype=torch.uint8, device=chunk.device)
+    if tuple(out.shape) != shape or out.dtype != out_dtype or not out.is_contiguous() or mask_out.numel() != b * t_ * tile * tile \
+            or not mask_out.is_contiguous():
+        raise ValueError("normalize_chunk_tiles: output buffers do not match the tiles")
+    check(_lib.load().frl_normalize_chunk_tiles(_p(chunk), _lib.F16 if chunk.dtype == torch.float16 else F32, t_, cy, cx, f, _p(desc), b, int(tile),
+                                                _p(table), _p(out), _dt(out), _p(mask_out), _stream()), "frl_normalize_chunk_tiles")
+    return out, mask_out
+
+
 @_timed("add")
 def add(a: torch.Tensor, b: torch.Tensor, scale_b: float = 1.0) -> torch.Tensor:
     """out = a + scale_b * b"""
