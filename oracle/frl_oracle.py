@@ -16,6 +16,10 @@ Pinning status
   reference's configs keep (frl/config/frl_model_v0.yaml:29-35,
   frl/config/frl_bindings_v0.yaml:887-891, scripts/train_vqvae.py:410-436) and
   are pinned by self-consistency tests only (fp64 brute force, gradcheck).
+* Tile ingest (per-channel normalisation + masking, ``normalize_tiles_np``): **parity
+  unpinned by the reference** -- FeatureBuilder / Normalizer import ``zarr`` (absent
+  in this image) and the reference keeps no fixture for them; restated from
+  frl/data/loaders/builders/feature_builder.py:487-548,709-737.
 
 All functions take a flat ``state`` dict with the reference's state-dict key
 names (frl/models/representation.py) and tensors in the reference's NCHW / NCT

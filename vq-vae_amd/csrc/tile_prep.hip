@@ -76,7 +76,14 @@ __global__ __launch_bounds__(256) void normalize_tiles_kernel(const TIN* __restr
   const int f0 = ((int)i0 & (lpr - 1)) * 8;
   FrlNormRec rec[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) rec[e] = table[f0 + e];
+  for (int e = 0; e < 8; ++e) {
+    rec[e] = table[f0 + e];
+    // disabled stages become exact no-ops so that the row loop is branch-free: x * 1 + (-0) == x bit for bit (also for x = -0),
+    // max(x, -inf) == min(x, +inf) == x
+    if (!(rec[e].flags & 1)) { rec[e].mul = 1.f; rec[e].add = -0.f; }
+    if (!(rec[e].flags & 2)) rec[e].lo = -__builtin_inff();
+    if (!(rec[e].flags & 4)) rec[e].hi = __builtin_inff();
+  }
   // every lane of a wave runs the same number of iterations (the shuffles below need all of them): pad the bound to whole waves
   const int64_t total_pad = (total + 63) & ~(int64_t)63;
   for (int64_t i = i0; i < total_pad; i += (int64_t)gridDim.x * 256) {
@@ -111,9 +118,9 @@ __global__ __launch_bounds__(256) void normalize_tiles_kernel(const TIN* __restr
     for (int e = 0; e < 8; ++e) {
 #pragma clang fp contract(off)                                     // numpy rounds the product before the sum: no fma here
       float x = (v[e] - rec[e].sub) / rec[e].div;                  // correctly rounded division (hipcc default)
-      if (rec[e].flags & 1) { const float prod = x * rec[e].mul; x = prod + rec[e].add; }
-      if (rec[e].flags & 2) x = fmaxf(x, rec[e].lo);
-      if (rec[e].flags & 4) x = fminf(x, rec[e].hi);
+      const float prod = x * rec[e].mul;
+      x = prod + rec[e].add;
+      x = __builtin_amdgcn_fmed3f(x, rec[e].lo, rec[e].hi);         // == min(max(x, lo), hi) for lo <= hi (checked on the host)
       r[e] = ok ? x : 0.f;
     }
     if (live) {

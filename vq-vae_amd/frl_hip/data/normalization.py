@@ -85,6 +85,10 @@ def norm_record(preset: NormPreset, stats: Optional[Mapping[str, float]] = None)
             lo, flags = float(preset.clamp["min"]), flags | FLAG_LO
         if preset.clamp.get("max") is not None:
             hi, flags = float(preset.clamp["max"]), flags | FLAG_HI
+    if (flags & FLAG_LO) and (flags & FLAG_HI) and lo > hi:
+        raise ValueError(f"clamp.min {lo} > clamp.max {hi}")
+    if not all(np.isfinite(v) for v in (sub, div, mul, add, lo, hi)) or div == 0.0:
+        raise ValueError("normalisation constants must be finite and the divisor non-zero")
     return sub, div, mul, add, lo, hi, flags
 
 
