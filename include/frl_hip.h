@@ -219,6 +219,11 @@ int frl_vq_bwd(const void* g_out, const void* z, const void* zq /* optional */, 
                int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
 int frl_vq_ema_update(const float* sums, const int32_t* counts, int K, int d, float decay, float eps, float* ema_count,
                       float* ema_sum, float* E, frl_stream_t stream);
+/* Dead-code revival of the legacy trainer's CodebookManager (scripts/train_vqvae.py:92,196-198 constructs and attaches it; the
+ * module is not in the reference tree -- build definition): codes with window_counts[k] < min_count are re-seeded with the
+ * encoder row z[splitmix64(seed + k) mod N], their AdamW moment rows m / v (optional) are cleared, *revived += number of codes. */
+int frl_vq_revive_dead_codes(float* E, const int64_t* window_counts, int64_t min_count, const void* z, int64_t N, int K, int d,
+                             uint64_t seed, float* m, float* v, int32_t* revived, int dtype, frl_stream_t stream);
 
 #ifdef __cplusplus
 }

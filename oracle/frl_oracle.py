@@ -541,3 +541,25 @@ def normalize_tiles_np(raw: np.ndarray, valid: Optional[np.ndarray], presets: li
             out[..., c] = normalize_channel_np(x[..., c], presets[c], stats[c])
     out = np.where(ok[..., None], out, np.float32(0.0))
     return out, ok.astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Dead-code revival (CodebookManager; the reference constructs it at scripts/train_vqvae.py:196-198 but does not ship the module:
+# build definition, **parity unpinned**).  Bit-level mirror of frl_vq_revive_dead_codes.
+# ---------------------------------------------------------------------------------------------------------------
+def splitmix64(x: int) -> int:
+    m = (1 << 64) - 1
+    x = (x + 0x9E3779B97F4A7C15) & m
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & m
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & m
+    return x ^ (x >> 31)
+
+
+def revive_dead_codes_np(codebook: np.ndarray, window_counts: np.ndarray, min_count: int, z_rows: np.ndarray, seed: int):
+    """-> (new codebook float32, boolean dead mask).  Code k with window_counts[k] < min_count takes z_rows[splitmix64(seed + k) % N]."""
+    out = codebook.astype(np.float32).copy()
+    dead = window_counts < min_count
+    n = z_rows.shape[0]
+    for k in np.nonzero(dead)[0]:
+        out[k] = z_rows[splitmix64((seed + int(k)) & ((1 << 64) - 1)) % n].astype(np.float32)
+    return out, dead

@@ -191,3 +191,53 @@ def test_hip_adamw_clip_matches_torch():
         for pr, pd in zip(ref, dev):
             assert (pd.detach().cpu() - pr.detach()).abs().max().item() <= 2e-6
     assert [dev[i] is p for i, p in zip(order, o_dev.params)] == [True] * 6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("K,d,N", [(64, 64, 1000), (512, 64, 4096), (37, 12, 77), (8192, 128, 300)])
+def test_vq_revive_dead_codes_matches_oracle(dtype, K, d, N):
+    from frl_hip import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(K + N)
+    cb = torch.randn(K, d, generator=g)
+    z = torch.randn(N, d, generator=g).to(dtype)
+    window = torch.randint(0, 4, (K,), generator=g, dtype=torch.int64)
+    m, v = torch.rand(K, d, generator=g), torch.rand(K, d, generator=g)
+    seed = (1 << 63) + 12345                                            # exercises the 64-bit wrap of seed + k
+    want, dead = O.revive_dead_codes_np(cb.numpy(), window.numpy(), 2, z.float().numpy(), seed)
+    cb_d, m_d, v_d = cb.to(dev), m.to(dev), v.to(dev)
+    revived = ops.vq_revive_dead_codes(cb_d, window.to(dev), 2, z.to(dev), seed, m_d, v_d)
+    assert int(revived.item()) == int(dead.sum()) and 0 < dead.sum() < K
+    assert np.array_equal(cb_d.cpu().numpy().view(np.uint32), want.view(np.uint32))          # bit-exact
+    dm = torch.from_numpy(dead)
+    assert not m_d.cpu()[dm].any() and not v_d.cpu()[dm].any()
+    assert torch.equal(m_d.cpu()[~dm], m[~dm]) and torch.equal(v_d.cpu()[~dm], v[~dm])
+    again = ops.vq_revive_dead_codes(cb_d, torch.full((K,), 5, dtype=torch.int64, device=dev), 2, z.to(dev), seed, revived=revived)
+    assert int(again.item()) == int(dead.sum())                        # nothing dead: nothing touched, counter unchanged
+    assert np.array_equal(cb_d.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_codebook_manager_revives_unused_codes_during_training():
+    from frl_hip.models import VQVAE
+    from frl_hip.training.codebook_manager import CodebookManager
+    from frl_hip.training.trainer import VQVAETrainer
+    dev = _dev()
+    torch.manual_seed(0)
+    m = VQVAE(in_features=64, codebook_size=64, emb_dim=64, type_encoder_dropout=0.0, phase_tcn_dropout=0.0,
+              compute_dtype=torch.bfloat16).to(dev)
+    with torch.no_grad():                                               # half of the codes far away from every encoder output
+        m.quant.codebook[32:] += 1000.0
+    mgr = CodebookManager(num_codes=m.quant.codebook_size, code_dim=m.quant.emb_dim, reset_every=2, min_count=1, seed=3)
+    m.attach_codebook_manager(mgr)
+    tr = VQVAETrainer(m, lr=1e-3, total_steps=10)
+    tiles = torch.randn(2, 5, 32, 32, 64, device=dev).bfloat16()
+    tr.step(tiles)
+    assert int(mgr.revived.item()) == 0 and int(mgr.window.sum().item()) == 2 * 32 * 32
+    assert m.quant.codebook[32:].abs().min().item() > 500
+    tr.step(tiles)                                                      # second step: the window closes, dead codes are re-seeded
+    assert int(mgr.revived.item()) >= 32 and int(mgr.window.sum().item()) == 0
+    assert m.quant.codebook.abs().max().item() < 100                    # the far-away codes are gone
+    out = tr.step(tiles)
+    assert torch.isfinite(out["loss"]).item()
+    idx = m.forward_tiles(tiles)["idx"]
+    assert (idx >= 32).any().item()                                     # revived codes are in use again

@@ -861,6 +861,34 @@ static int vq_bwd_chunk(int K, int d) {
   return kc;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Dead-code revival (CodebookManager of the legacy trainer, scripts/train_vqvae.py:92,196-198; the manager module itself is not
+// in the reference tree -- build definition): a code whose usage count over the manager's window is below `min_count` is re-seeded
+// with an encoder output row of the current batch, row index = splitmix64(seed + k) mod N; its AdamW moments are cleared so the
+// stale momentum does not drag the new vector back.  One workgroup per code, no host round trip; `revived` counts them.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long vq_splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+template <typename T>
+__global__ __launch_bounds__(64) void vq_revive_kernel(float* __restrict__ E, const long long* __restrict__ window_counts, long long min_count,
+                                                       const T* __restrict__ z, long long N, int K, int d, unsigned long long seed,
+                                                       float* __restrict__ m, float* __restrict__ v, int* __restrict__ revived) {
+  const int k = blockIdx.x;
+  if (k >= K || window_counts[k] >= min_count) return;
+  const unsigned long long r = vq_splitmix64(seed + (unsigned long long)k) % (unsigned long long)N;
+  for (int j = threadIdx.x; j < d; j += 64) {
+    E[(size_t)k * d + j] = to_f32(z[(size_t)r * d + j]);
+    if (m != nullptr) m[(size_t)k * d + j] = 0.f;
+    if (v != nullptr) v[(size_t)k * d + j] = 0.f;
+  }
+  if (threadIdx.x == 0) atomicAdd(revived, 1);
+}
+
 extern "C" {
 
 size_t frl_vq_workspace_bytes(int64_t N, int K, int d) {
@@ -937,6 +965,22 @@ int frl_vq_ema_update(const float* sums, const int32_t* counts, int K, int d, fl
                       float* ema_sum, float* E, hipStream_t stream) {
   FRL_LAUNCH(vq_ema_kernel, dim3(1), dim3(256), 0, stream, sums, counts, K, d, decay, eps, ema_count, ema_sum, E);
   return frl_check_launch("vq_ema_update");
+}
+
+// E [K][d] float32 codebook (updated in place), window_counts [K] int64, z [N][d] rows of `dtype`, m / v optional AdamW moment
+// rows of the codebook, revived: device int32 incremented by the number of re-seeded codes.
+int frl_vq_revive_dead_codes(float* E, const int64_t* window_counts, int64_t min_count, const void* z, int64_t N, int K, int d,
+                             uint64_t seed, float* m, float* v, int32_t* revived, int dtype, hipStream_t stream) {
+  if (K <= 0 || d <= 0) return frl_fail(-2, "vq_revive_dead_codes: bad codebook shape");
+  if (N <= 0) return frl_fail(-2, "vq_revive_dead_codes: no candidate rows");
+  if (dtype == FRL_F32)
+    FRL_LAUNCH((vq_revive_kernel<float>), dim3(K), dim3(64), 0, stream, E, (const long long*)window_counts, (long long)min_count,
+               (const float*)z, (long long)N, K, d, (unsigned long long)seed, m, v, revived);
+  else if (dtype == FRL_BF16)
+    FRL_LAUNCH((vq_revive_kernel<bf16>), dim3(K), dim3(64), 0, stream, E, (const long long*)window_counts, (long long)min_count,
+               (const bf16*)z, (long long)N, K, d, (unsigned long long)seed, m, v, revived);
+  else return frl_fail(-2, "vq_revive_dead_codes: dtype must be FRL_F32 or FRL_BF16");
+  return frl_check_launch("vq_revive_dead_codes");
 }
 
 }  // extern "C"

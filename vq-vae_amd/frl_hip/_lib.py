@@ -38,6 +38,7 @@ SIGNATURES = {
     "frl_vq_assign_fwd": (c_int, [P, P, L, I, I, P, P, P, P, I, P, S, P]),
     "frl_vq_bwd": (c_int, [P, P, P, P, P, P, P, F, L, I, I, P, P, P, I, P, S, P]),
     "frl_vq_ema_update": (c_int, [P, P, I, I, F, F, P, P, P, P]),
+    "frl_vq_revive_dead_codes": (c_int, [P, P, L, P, L, I, I, ctypes.c_uint64, P, P, P, I, P]),
     "frl_groupnorm_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, F, I, I, P]),
     "frl_groupnorm_bwd_workspace_bytes": (S, [I, I, I]),
     "frl_groupnorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P, S, P]),

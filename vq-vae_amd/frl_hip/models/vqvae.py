@@ -76,6 +76,7 @@ class VQVAE(RepresentationModel):
             if phase_codebook_size:
                 self.quant_phase = VectorQuantizer(phase_codebook_size, self.z_phase_dim, beta, quantizer, ema_decay, ema_eps)
         self.codebook_manager = None
+        self._manager_takes_rows = False
         self.fused_decoder = True
         # The phase path is conditioned on stopgrad(z_type): forward AND backward of the two branches are independent, so the phase
         # branch runs on a side HIP stream next to VQ + type decoder (forward) and next to the whole type-path backward.
@@ -88,8 +89,12 @@ class VQVAE(RepresentationModel):
         return self._side_stream
 
     def attach_codebook_manager(self, manager) -> None:
-        """scripts/train_vqvae.py:197-198: the manager tracks usage / dead codes from `quant.last_counts`."""
+        """scripts/train_vqvae.py:197-198: the manager tracks usage / dead codes from `quant.last_counts`; a manager whose
+        `update` takes a second argument (training.codebook_manager.CodebookManager) also receives the encoder rows for revival."""
+        import inspect
         self.codebook_manager = manager
+        upd = getattr(manager, "update", None)
+        self._manager_takes_rows = upd is not None and len(inspect.signature(upd).parameters) >= 2
 
     def _decode_loss(self, dec: Conv2DHead, z: torch.Tensor, target: torch.Tensor, mask, want_recon: bool):
         """Decoder + masked L2.  Hot configuration (bf16, hidden 128, 64 features): one fused kernel per direction, the
@@ -168,8 +173,11 @@ class VQVAE(RepresentationModel):
             loss = loss + ph.pop("loss_terms")
             out.update(ph)
         out["loss"] = loss
-        if self.codebook_manager is not None and hasattr(self.codebook_manager, "update"):
-            self.codebook_manager.update(self.quant.last_counts)
+        if self.codebook_manager is not None and hasattr(self.codebook_manager, "update") and self.training:
+            if self._manager_takes_rows:
+                self.codebook_manager.update(self.quant.last_counts, z_type.detach().reshape(-1, d))
+            else:                                                           # a manager with the bare update(counts) signature
+                self.codebook_manager.update(self.quant.last_counts)
         return out
 
     def forward(self, batch, return_gate: bool = False):

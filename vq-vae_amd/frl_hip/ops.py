@@ -310,6 +310,30 @@ def mean_time(tile: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_timed("vq_revive_dead_codes")
+def vq_revive_dead_codes(codebook: torch.Tensor, window_counts: torch.Tensor, min_count: int, z_rows: torch.Tensor, seed: int,
+                         exp_avg: Optional[torch.Tensor] = None, exp_avg_sq: Optional[torch.Tensor] = None,
+                         revived: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """In place: codebook[k] = z_rows[splitmix64(seed + k) % N] for every code with window_counts[k] < min_count; clears the AdamW
+    moment rows of those codes; returns the device int32 counter `revived` (incremented).  No host synchronisation."""
+    k, d = codebook.shape
+    if codebook.dtype != torch.float32 or not codebook.is_contiguous():
+        raise ValueError("vq_revive_dead_codes: codebook must be contiguous float32 [K, d]")
+    if window_counts.dtype != torch.int64 or window_counts.numel() != k or window_counts.device != codebook.device:
+        raise ValueError("vq_revive_dead_codes: window_counts must be int64 [K] on the codebook's device")
+    if z_rows.dim() != 2 or z_rows.shape[1] != d or not z_rows.is_contiguous() or z_rows.device != codebook.device:
+        raise ValueError("vq_revive_dead_codes: z_rows must be contiguous [N, d] on the codebook's device")
+    for mom in (exp_avg, exp_avg_sq):
+        if mom is not None and (mom.dtype != torch.float32 or mom.shape != codebook.shape or not mom.is_contiguous()):
+            raise ValueError("vq_revive_dead_codes: AdamW moments must match the codebook")
+    if revived is None:
+        revived = torch.zeros(1, dtype=torch.int32, device=codebook.device)
+    check(_lib.load().frl_vq_revive_dead_codes(_p(codebook), _p(window_counts), int(min_count), _p(z_rows), z_rows.shape[0], k, d,
+                                               int(seed) & 0xFFFFFFFFFFFFFFFF, _p(exp_avg), _p(exp_avg_sq), _p(revived), _dt(z_rows),
+                                               _stream()), "frl_vq_revive_dead_codes")
+    return revived
+
+
 @_timed("normalize_tiles")
 def normalize_tiles(raw: torch.Tensor, table: torch.Tensor, valid: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.bfloat16,
                     out: Optional[torch.Tensor] = None, mask_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -97,6 +97,9 @@ class VQVAETrainer:
         else:
             out["grad_norm"] = torch.nn.utils.clip_grad_norm_(self.params, self.max_norm)
             self.opt.step()
+        mgr = getattr(self.model, "codebook_manager", None)
+        if mgr is not None and hasattr(mgr, "after_step"):                   # dead-code revival every `reset_every` steps, on the device
+            mgr.after_step(self.model.quant, self.opt)
         self.step_idx += 1
         out["lr"] = lr_now
         return out
