@@ -335,7 +335,63 @@ def test_tcn_hot_dropout1d_mask_matches_float64(B, HW, dil, p):
         ref = ref_st[pfx + nm].grad
         assert rel_err(gr[kk].reshape(ref.shape), ref) <= 2e-2, kk
     with pytest.raises(NotImplementedError):
-        ops.tcn_block_fwd(xd[:, :4].contiguous(), *args, dil, G, drop_mask=md)                     # T != 5: generic kernels, no dropout
+        ops.tcn_block_fwd(xd[:, :4].contiguous(), *args, dil, G, drop_mask=md)                     # T != 5: the raw generic kernels take no mask
+
+
+@pytest.mark.parametrize("dtype,T,cin,cout,G,tol", [(torch.float32, 5, 32, 32, 8, 2e-5), (torch.bfloat16, 10, 64, 64, 8, 2e-2),
+                                                    (torch.float32, 7, 8, 16, 4, 2e-5), (torch.float32, 5, 8, 8, 4, 2e-5)])
+def test_gated_block_dropout1d_outside_the_hot_configuration(monkeypatch, dtype, T, cin, cout, G, tol):
+    """Training-mode Dropout1d for shapes the hot kernels do not cover (float32 parity mode, T != 5, projection blocks): the module's
+    two-input formulation on the generic kernels vs float64 autograd of the same mask realisation (tcn.py:89-110)."""
+    from frl_hip.models import blocks
+    B, HW, dil, p = 2, 96, 2, 0.3
+    g = torch.Generator().manual_seed(T * cin + cout)
+    blk = blocks.GatedResidualBlock(cin, cout, 3, dil, dropout_rate=p, num_groups=G).to(DEV)
+    with torch.no_grad():
+        for prm in blk.parameters():
+            prm.copy_((torch.randn(prm.shape, generator=g) * (0.3 if prm.dim() > 1 else 0.2) + (1.0 if prm.dim() == 1 and prm is blk.norm.weight else 0.0)).to(DEV))
+    mask = ((torch.rand(B, HW, cin, generator=g) >= p).float() / (1.0 - p))
+    monkeypatch.setattr(blocks, "dropout_mask", lambda shape, rate, like: mask.to(like.dtype).to(like.device))
+    blk.train()
+    x = q(torch.randn(B, T, HW, cin, generator=g), dtype)
+    xd = x.to(dtype).to(DEV).requires_grad_(True)
+    y = blk(xd)
+    dy = q(torch.randn(B, T, HW, cout, generator=g), dtype)
+    y.backward(dy.to(dtype).to(DEV))
+    # float64 reference of the same realisation
+    st = {k: v.detach().double().cpu() for k, v in blk.state_dict().items()}
+    if dtype == torch.bfloat16:
+        for k in ("conv.weight", "gate.weight", "projection.weight"):
+            if k in st:
+                st[k] = q(st[k].float(), dtype)
+    ref = {k: v.clone().requires_grad_(True) for k, v in st.items()}
+    xr = x.double().requires_grad_(True)
+    mk = q(mask, dtype)
+    xm = xr * mk.unsqueeze(1)
+    if dtype == torch.bfloat16:
+        xm = xm + (q(xm.detach().float(), dtype) - xm.detach())
+    to_nct = lambda a: a.permute(0, 2, 3, 1).reshape(B * HW, a.shape[-1], T)                       # noqa: E731
+    out = torch.nn.functional.conv1d(to_nct(xm), ref["conv.weight"], ref["conv.bias"], padding=dil, dilation=dil)
+    out = O.group_norm(out, G, ref["norm.weight"], ref["norm.bias"])
+    gate = torch.sigmoid(torch.nn.functional.conv1d(out, ref["gate.weight"], ref["gate.bias"]))
+    res = to_nct(xr)
+    if "projection.weight" in ref:
+        res = torch.nn.functional.conv1d(res, ref["projection.weight"], ref["projection.bias"])
+    yr = (gate * torch.relu(out) + (1 - gate) * res).reshape(B, HW, cout, T).permute(0, 3, 1, 2)
+    yr.backward(dy)
+    assert rel_err(y.float(), yr.detach()) <= tol
+    assert rel_err(xd.grad.float(), xr.grad) <= 10 * tol
+    for name, prm in blk.named_parameters():
+        assert rel_err(prm.grad.float().reshape(ref[name].shape), ref[name].grad) <= 10 * tol, name
+    blk.eval()
+    assert rel_err(blk(xd).float(), y.float().cpu()) > 1e-2                                         # eval mode: no dropout
+
+
+def test_gated_block_dropout1d_f32_64_channels_is_refused_up_front():
+    from frl_hip.models import blocks
+    blk = blocks.GatedResidualBlock(64, 64, 3, 1, dropout_rate=0.2, num_groups=8).to(DEV).train()
+    with pytest.raises(NotImplementedError):                                                        # before any kernel runs, not in backward
+        blk(torch.randn(1, 5, 16, 64, device=DEV))
 
 
 def test_channel_scale_dropout2d():

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as Fh
+from .. import ops
 from ..functional import ACT_NONE, ACT_RELU, ACT_SIGMOID
 
 
@@ -216,8 +217,44 @@ class GatedResidualBlock(nn.Module):
             mask = dropout_mask((x.shape[0],) + tuple(x.shape[2:]), min(self.dropout.p, 1.0 - 1e-6), x)
         pw = self.projection.weight if self.needs_projection else None
         pb = self.projection.bias if self.needs_projection else None
+        if mask is not None and not ops.tcn_hot_supported(x, self.in_channels, self.out_channels, self.norm.num_groups, self.dilation,
+                                                          self.needs_projection):
+            return self._forward_masked_generic(x, mask, pw, pb)
         return Fh.TcnBlockFn.apply(x, self.conv.weight, self.conv.bias, self.norm.weight, self.norm.bias, self.gate.weight,
                                    self.gate.bias, pw, pb, self.dilation, self.norm.num_groups, self.norm.eps, mask)
+
+    def _forward_masked_generic(self, x: torch.Tensor, mask: torch.Tensor, pw, pb) -> torch.Tensor:
+        """Dropout1d for shapes outside the hot configuration (float32 parity mode, T != 5, other widths).  The generic kernels have
+        one input, so the block is evaluated on the concatenation [x .* mask | x] with the conv weights padded by zeros over the second
+        half and the residual projection padded by zeros over the first: conv sees the dropped-out series, the residual the untouched
+        one (identity residual = an identity projection), exactly tcn.py:89-110.  Gradients flow through the same kernels."""
+        shape = x.shape
+        b, t, c = shape[0], shape[1], shape[-1]
+        if 2 * c > 128:
+            raise NotImplementedError("TCN Dropout1d outside the hot configuration needs 2 * C_in <= 128 channels")
+        # the generic backward kernel keeps conv, gate and projection weights of the doubled input in LDS (csrc/tcn_bwd.hip)
+        f32 = x.dtype == torch.float32
+        pad = lambda n, lo: next(v for v in (16, 32, 64, 128) if v >= max(n, lo))          # noqa: E731
+        pi, po = pad(2 * c, 16 if f32 else 32), pad(self.out_channels, 16 if f32 else 32)
+        nfi, mbo = (pi // 4 if f32 else pi // 32), po // 16
+        nfo = 4 * mbo if f32 else max(1, mbo // 2)
+        lds = (3 * mbo * nfi + 2 * mbo * nfo + mbo * nfi) * 64 * (4 if f32 else 16) + 48 * 4 * mbo * 4
+        if lds > 160 * 1024:
+            raise NotImplementedError(f"TCN Dropout1d with {c} -> {self.out_channels} channels in {x.dtype} does not fit the generic backward "
+                                      "kernel's LDS; use bf16 compute (or dropout 0.0) for this width")
+        x4 = x.reshape(b, t, -1, c)
+        m3 = mask.reshape(b, -1, c)
+        xm = Fh.FilmFn.apply(x4, m3, torch.zeros_like(m3))                                 # x .* mask, broadcast over time
+        x_aug = torch.cat([xm, x4], dim=-1)
+        w = self.conv.weight
+        w_aug = torch.cat([w, torch.zeros_like(w)], dim=1)
+        if pw is None:
+            pw = torch.eye(c, dtype=w.dtype, device=w.device).reshape(c, c, 1)
+            pb = torch.zeros(c, dtype=w.dtype, device=w.device)
+        p_aug = torch.cat([torch.zeros_like(pw), pw], dim=1)
+        y = Fh.TcnBlockFn.apply(x_aug, w_aug, self.conv.bias, self.norm.weight, self.norm.bias, self.gate.weight, self.gate.bias,
+                                p_aug, pb, self.dilation, self.norm.num_groups, self.norm.eps, None)
+        return y.reshape(shape[:-1] + (self.out_channels,))
 
 
 class TCNEncoder(nn.Module):

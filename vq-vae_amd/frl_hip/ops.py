@@ -487,18 +487,23 @@ def edge_smooth_bwd(d_smoothed, x, a_soft, b_soft, rank: int, coarse_dilation: i
 # ----------------------------------------------------------------------------------------------
 # fused TCN block (csrc/tcn_fwd.hip, tcn_bwd.hip); x [B,T,HW..,Cin]
 # ----------------------------------------------------------------------------------------------
-@_timed("tcn_block_fwd")
+def tcn_hot_supported(x: torch.Tensor, cin: int, cout: int, groups: int, dilation: int, has_projection: bool) -> bool:
+    """True when the block on x [B,T,..,Cin] runs on the specialised `tcn_hot_*` kernels (the only ones that take a Dropout1d mask)."""
+    return bool(_lib.load().frl_tcn_hot_supported(x.shape[1], cin, cout, groups, dilation, int(has_projection), _dt(x)))
+
+
 def _check_drop_mask(drop_mask, x, hot: bool):
     if drop_mask is None:
         return
     if not hot:
-        raise NotImplementedError("TCN Dropout1d (p > 0, training) is implemented for the hot configuration only "
-                                  "(bf16, 64 channels, T = 5, 8 groups, dilation 1/2/4); configure phase_tcn dropout 0.0 otherwise")
+        raise NotImplementedError("the generic TCN kernels take no Dropout1d mask (only the hot configuration: bf16, 64 channels, T = 5, "
+                                  "8 groups, dilation 1/2/4); GatedResidualBlock routes other shapes through its two-input formulation")
     b, t, c = x.shape[0], x.shape[1], x.shape[-1]
     if drop_mask.dtype != x.dtype or not drop_mask.is_contiguous() or drop_mask.numel() != x.numel() // t:
         raise ValueError("drop_mask must be a contiguous [B, HW.., C] tensor of x's dtype")
 
 
+@_timed("tcn_block_fwd")
 def tcn_block_fwd(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, dilation: int, groups: int,
                   eps: float = 1e-5, allow_hot: bool = True, drop_mask=None):
     b, t, cin = x.shape[0], x.shape[1], x.shape[-1]
