@@ -22,6 +22,11 @@ from .blocks import Conv2DHead
 from .representation import RepresentationModel
 
 
+def _weighted(weight: float, term: torch.Tensor) -> torch.Tensor:
+    """weight * term; a weight of exactly 1.0 (the default) costs no kernel in forward or backward."""
+    return term if weight == 1.0 else weight * term
+
+
 class VectorQuantizer(nn.Module):
     """argmin-L2 codebook lookup with straight-through estimator; 'st' (gradient) or 'ema' codebook updates."""
 
@@ -118,14 +123,14 @@ class VQVAE(RepresentationModel):
         if hasattr(self, "quant_phase"):
             zpq, pvq, pperp, pidx = self.quant_phase(z_phase.reshape(-1, z_phase.shape[-1]))
             zp_in = zpq.reshape(z_phase.shape)
-            terms = self.lambda_vq * pvq
+            terms = _weighted(self.lambda_vq, pvq)
             out.update(idx_phase=pidx, vq_loss_phase=pvq, perplexity_phase=pperp)
         if mask is None or mask.dim() == 4:                                 # [B,T,H,W]: per-observation validity from the tile ingest
             pmask = mask
         else:
             pmask = mask.unsqueeze(1).expand(b, t, hh, ww).contiguous()
         l_phase, xhat_phase = self._decode_loss(self.decoder_phase, zp_in, tile, pmask, return_recon)
-        terms = self.lambda_recon * l_phase if terms is None else terms + self.lambda_recon * l_phase
+        terms = _weighted(self.lambda_recon, l_phase) if terms is None else terms + _weighted(self.lambda_recon, l_phase)
         out.update(z_phase=z_phase, l_phase=l_phase, loss_terms=terms)
         if xhat_phase is not None:
             out["xhat_phase"] = xhat_phase
@@ -161,7 +166,7 @@ class VQVAE(RepresentationModel):
         out = dict(z_type=z_type, gate=gate, idx=idx, vq_loss=vq_loss, perplexity=perp, l_type=l_type)
         if xhat_type is not None:
             out["xhat_type"] = xhat_type
-        loss = self.lambda_recon * l_type + self.lambda_vq * vq_loss
+        loss = _weighted(self.lambda_recon, l_type) + _weighted(self.lambda_vq, vq_loss)
         if self.phase:
             if side is not None:
                 main.wait_stream(side)
