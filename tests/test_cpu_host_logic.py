@@ -178,3 +178,61 @@ def test_norm_records_equal_the_per_channel_oracle(features, dtype):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
     with pytest.raises(ValueError):
         NormPreset.from_dict({"type": "whiten"})
+
+
+# ------------------------------------------------------------------------------------------------ checkpoints
+def test_checkpoint_rotation_reproduces_the_reference_manager(golden_dir, tmp_path):
+    """tests/golden/checkpoint_policy.json: directory listings after every epoch, produced by the reference's CheckpointManager."""
+    import json
+    from frl_hip.training.checkpointing import CheckpointManager, CheckpointPolicy
+    nan = float("nan")
+
+    def save_fn(state, path):
+        with open(path, "w") as fh:
+            json.dump({k: (None if isinstance(v, float) and v != v else v) for k, v in state.items()}, fh)
+
+    def load_fn(path):
+        with open(path) as fh:
+            return {k: (nan if v is None else v) for k, v in json.load(fh).items()}
+
+    for case in json.load(open(os.path.join(golden_dir, "checkpoint_policy.json"))):
+        d = tmp_path / case["name"]
+        pol = CheckpointPolicy(**case["cfg"])
+        mgr = CheckpointManager(d, pol, save_fn, load_fn)
+        values = [nan if v is None else v for v in case["values"]]
+        for ep, v in enumerate(values):
+            mgr.save(ep, {"epoch": ep + 1, pol.monitor: v}, {pol.monitor: v})
+            assert sorted(os.listdir(d)) == case["listings"][ep], (case["name"], ep)
+        mgr2 = CheckpointManager(d, pol, save_fn, load_fn)                      # restart: top-k list rebuilt from disk
+        mgr2.restore_top_k()
+        for j, v in enumerate(case["resume_values"]):
+            ep = len(values) + j
+            mgr2.save(ep, {"epoch": ep + 1, pol.monitor: v}, {pol.monitor: v})
+            assert sorted(os.listdir(d)) == case["listings"][ep], (case["name"], "resume", j)
+        with pytest.raises(KeyError):
+            mgr2.save(99, {}, {"other": 1.0})
+
+
+def test_checkpoint_state_round_trip(tmp_path):
+    """The dict has the reference's keys, loads with weights_only=True, and `from_checkpoint`-style fields survive."""
+    from frl_hip.training.checkpointing import CheckpointManager, CheckpointPolicy, build_checkpoint_state, resume_from_checkpoint
+    torch.manual_seed(0)
+    model = torch.nn.Linear(4, 3)
+    model.type_in_channels, model.phase_in_channels = 4, 4
+    opt = torch.optim.AdamW(model.parameters(), lr=3e-4)
+    model(torch.randn(2, 4)).sum().backward()
+    opt.step()
+    state = build_checkpoint_state(model, opt, epoch=6, metrics={"val/loss": 0.25}, model_config={"version": "4"},
+                                   scheduler_state={"last_epoch": 7})
+    assert {"epoch", "model_version", "model_config", "type_in_channels", "phase_in_channels", "model_state_dict", "optimizer_state_dict",
+            "scheduler_state_dict", "val/loss"} <= set(state) and state["epoch"] == 7 and state["model_version"] == "4"
+    mgr = CheckpointManager(tmp_path, CheckpointPolicy(monitor="val/loss", save_every_n_epochs=7))
+    mgr.save(6, state, {"val/loss": 0.25})
+    assert sorted(os.listdir(tmp_path)) == ["encoder_best_1_epoch_007.pt", "encoder_epoch_007.pt", "encoder_last.pt"]
+    m2 = torch.nn.Linear(4, 3)
+    o2 = torch.optim.AdamW(m2.parameters(), lr=1.0)
+    mgr2 = CheckpointManager(tmp_path, CheckpointPolicy(monitor="val/loss"))
+    start, lr, sched = resume_from_checkpoint(m2, o2, tmp_path, manager=mgr2)
+    assert start == 7 and abs(lr - 3e-4) < 1e-12 and sched == {"last_epoch": 7} and len(mgr2.best) == 1
+    assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), m2.state_dict().values()))
+    assert resume_from_checkpoint(m2, o2, tmp_path, no_resume=True)[0] == 0

@@ -331,3 +331,28 @@ def test_two_rank_data_parallel_matches_single_process(golden_dir, tmp_path):
     for n, p in m.named_parameters():
         ref = p.detach().cpu().numpy()
         assert np.abs(got[n] - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), n
+
+
+def test_checkpoint_resume_continues_the_trajectory(golden_dir, tmp_path):
+    """Reference-format checkpoint (model + HipAdamW state) written after two steps; a fresh trainer resumed from it takes the same
+    third step as the original, bit for bit."""
+    from frl_hip.training.checkpointing import CheckpointManager, CheckpointPolicy, build_checkpoint_state, resume_from_checkpoint
+    from frl_hip.training.trainer import VQVAETrainer
+    fx = _load(golden_dir, "vqvae_tiny_seed0")
+    tiles = torch.from_numpy(fx["tiles"]).float().to(DEV)
+    m = _vqvae_from_fixture(fx)
+    tr = VQVAETrainer(m, lr=1e-3, total_steps=10)
+    for i in range(2):
+        tr.step(tiles[i])
+    mgr = CheckpointManager(tmp_path, CheckpointPolicy(monitor="train/loss"))
+    mgr.save(0, build_checkpoint_state(m, tr.opt, epoch=0, metrics={"train/loss": 1.0}), {"train/loss": 1.0})
+    want = tr.step(tiles[2])["loss"].item()
+    m2 = _vqvae_from_fixture(fx)
+    tr2 = VQVAETrainer(m2, lr=1e-3, total_steps=10)
+    start, _, _ = resume_from_checkpoint(m2, tr2.opt, tmp_path, device=DEV)
+    assert start == 1
+    tr2.step_idx = 2                                                     # the LR schedule position travels with the caller's step count
+    got = tr2.step(tiles[2])["loss"].item()
+    assert got == want
+    for (n, a), (_, b) in zip(m.named_parameters(), m2.named_parameters()):
+        assert torch.equal(a, b), n
