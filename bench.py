@@ -29,8 +29,8 @@ MFMA_BF16_PEAK_TF = 2500.0   # dense bf16
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="tiles per GPU (weak scaling)")
     ap.add_argument("--codebook", type=int, default=512)
     ap.add_argument("--emb-dim", type=int, default=64)
