@@ -236,3 +236,17 @@ def test_checkpoint_state_round_trip(tmp_path):
     assert start == 7 and abs(lr - 3e-4) < 1e-12 and sched == {"last_epoch": 7} and len(mgr2.best) == 1
     assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), m2.state_dict().values()))
     assert resume_from_checkpoint(m2, o2, tmp_path, no_resume=True)[0] == 0
+
+
+def test_denormalize_inverts_the_ingest_normalisation():
+    import frl_oracle as O
+    from frl_hip.data.normalization import NormPreset
+    from frl_hip.training.export import denormalize
+    from tile_cases import PRESET_CYCLE
+    pairs = [(p, s) for p, s in PRESET_CYCLE if not (p.get("clamp") or {}).get("enabled") and p.get("in_min") != p.get("in_max") or p["type"] == "identity"]
+    presets, stats = [p for p, _ in pairs], [s for _, s in pairs]
+    raw = np.random.default_rng(0).standard_normal((50, len(pairs))).astype(np.float32)
+    normed, mask = O.normalize_tiles_np(raw, None, presets, stats)
+    assert mask.all()
+    back = denormalize(normed, [NormPreset.from_dict(p) for p in presets], stats)
+    assert np.abs(back - raw).max() < 1e-5

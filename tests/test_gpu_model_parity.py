@@ -1,5 +1,6 @@
 """Model-level parity on the GPU: frl_hip RepresentationModel / VQVAE vs the golden vectors generated from the reference
 (encoder: pinned) and vs the oracle's VQ-VAE step (quantizer / decoder: parity unpinned by the reference)."""
+import json
 import os
 
 import numpy as np
@@ -356,3 +357,28 @@ def test_checkpoint_resume_continues_the_trajectory(golden_dir, tmp_path):
     assert got == want
     for (n, a), (_, b) in zip(m.named_parameters(), m2.named_parameters()):
         assert torch.equal(a, b), n
+
+
+def test_export_codebook_bundle(tmp_path):
+    from frl_hip.data.normalization import NormPreset
+    from frl_hip.models import VQVAE
+    from frl_hip.training.export import decode_codebook, export_codebook
+    torch.manual_seed(0)
+    m = VQVAE(in_features=64, codebook_size=32, emb_dim=64, compute_dtype=torch.float32).to(DEV)
+    with torch.no_grad():
+        m.quant.codebook.copy_(torch.randn(32, 64))
+    dec = decode_codebook(m)
+    sd = {k: v.detach().double().cpu() for k, v in m.state_dict().items()}
+    ref = O.decoder_forward(sd, sd["quant.codebook"].reshape(1, 32, 1, 64).permute(0, 3, 1, 2), "decoder_type.").permute(0, 2, 3, 1).reshape(32, 64)
+    assert maxabs(dec, ref) < 1e-5
+    names = [f"f{i:03d}" for i in range(64)]
+    presets = [NormPreset("zscore")] * 64
+    stats = [{"mean": float(i), "sd": 2.0} for i in range(64)]
+    path = export_codebook(m, tmp_path / "cb", names, presets, stats, usage=torch.full((32,), 1 / 32), years=[2001, 2002], csv=True)
+    z = np.load(path)
+    assert z["cont_KT"].shape == (64, 64) and z["code_id"].tolist()[:3] == [0, 0, 1] and z["year"].tolist()[:3] == [2001, 2002, 2001]
+    assert np.abs(z["cont_KT"][0] - (dec[0].cpu().numpy() * 2.0 + np.arange(64))).max() < 1e-4
+    assert z["codes_K3"].shape == (32, 3) and abs(z["codes_K3"][5, 1] - 1 / 32) < 1e-12
+    meta = json.loads(str(z["meta"]))
+    assert meta["K"] == 32 and meta["T"] == 2 and meta["cont_names"] == names
+    assert (tmp_path / "cb_cont_KT.csv").exists() and (tmp_path / "cb_codes_K3.csv").exists()
