@@ -225,6 +225,16 @@ int frl_vq_ema_update(const float* sums, const int32_t* counts, int K, int d, fl
 int frl_vq_revive_dead_codes(float* E, const int64_t* window_counts, int64_t min_count, const void* z, int64_t N, int K, int d,
                              uint64_t seed, float* m, float* v, int32_t* revived, int dtype, frl_stream_t stream);
 
+/* ---- mutual k-nearest-neighbour pair mining -----------------------------------------------------
+ * frl/losses/pairs.py:531-610 pairs_mutual_knn_chunked: per anchor the k nearest anchors by L2 distance in feature space, excluding
+ * itself and same-patch anchors closer than pos_min_spatial pixels; knn_idx [N][k] in ascending distance (ties: lower index),
+ * -1 where fewer than k candidates remain; mutual[i][r] = 1 iff i is also among the neighbours of knn_idx[i][r].
+ * feat [N][D] float32 with D in {16, 32, 48, 64, 96, 128, 256} (pad narrower features with zero columns), patch_id [N] int32,
+ * coords [N][2] float32 (row, col).  N is bounded by frl_mutual_knn_max_points(D) (four distance rows share the LDS). */
+size_t frl_mutual_knn_max_points(int D);
+int frl_mutual_knn(const float* feat, int N, int D, const int32_t* patch_id, const float* coords, float pos_min_spatial, int k,
+                   int32_t* knn_idx, uint8_t* mutual, frl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

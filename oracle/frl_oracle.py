@@ -563,3 +563,30 @@ def revive_dead_codes_np(codebook: np.ndarray, window_counts: np.ndarray, min_co
     for k in np.nonzero(dead)[0]:
         out[k] = z_rows[splitmix64((seed + int(k)) & ((1 << 64) - 1)) % n].astype(np.float32)
     return out, dead
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Mutual kNN pair mining -- restatement of pairs_mutual_knn_chunked (frl/losses/pairs.py:531-610) in float64 numpy with the
+# (distance, index) tie rule.  **Pinned**: tests/golden/mutual_knn_*.npz hold the reference function's own output
+# (oracle/make_pairs_golden.py imports it); the restatement equals it on those inputs.
+# ---------------------------------------------------------------------------------------------------------------
+def mutual_knn_pairs_np(features: np.ndarray, coord_list: list, offsets: list, k: int, pos_min_spatial: float = 4.0):
+    """-> (pairs [P, 2] int64 ordered by anchor then neighbour rank, knn_idx [N, k] int64 with -1 padding)."""
+    x = features.astype(np.float64)
+    n = x.shape[0]
+    d2 = ((x[:, None, :] - x[None, :, :]) ** 2).sum(-1)
+    np.fill_diagonal(d2, np.inf)                                                  # pairs.py:573-575
+    for p, cp in enumerate(coord_list):                                           # pairs.py:577-588
+        ps, pe = offsets[p], offsets[p + 1]
+        c = np.asarray(cp, dtype=np.float32).reshape(-1, 2)
+        sp = np.sqrt(((c[:, None, :] - c[None, :, :]) ** 2).sum(-1, dtype=np.float32))
+        blk = d2[ps:pe, ps:pe]
+        blk[sp < np.float32(pos_min_spatial)] = np.inf
+    knn = np.full((n, k), -1, dtype=np.int64)
+    kk = min(k, n - 1)
+    for i in range(n):                                                            # pairs.py:590-594
+        order = np.lexsort((np.arange(n), d2[i]))[:kk]
+        order = np.where(np.isinf(d2[i][order]), -1, order)
+        knn[i, :kk] = order
+    pairs = [(i, int(j)) for i in range(n) for j in knn[i] if j >= 0 and (knn[j] == i).any()]     # pairs.py:596-610
+    return np.asarray(pairs, dtype=np.int64).reshape(-1, 2), knn

@@ -176,3 +176,16 @@ def test_oracle_vqvae_step_fixture(golden_dir):
     tr = O.OracleTrainer(sd, hp, lr=1e-3, total_steps=10)
     traj = [float(tr.step(tiles[i])["loss"]) for i in range(3)]
     assert np.abs(np.asarray(traj) - fx["traj"]).max() < 1e-10
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+def test_oracle_mutual_knn_equals_reference_output(golden_dir, case):
+    """tests/golden/mutual_knn_*.npz: pairs returned by the reference's pairs_mutual_knn_chunked (oracle/make_pairs_golden.py)."""
+    import frl_oracle as O
+    fx = np.load(os.path.join(golden_dir, f"mutual_knn_{case}.npz"))
+    offsets = fx["offsets"].tolist()
+    coords = [fx["coords"][offsets[p]:offsets[p + 1]] for p in range(len(offsets) - 1)]
+    pairs, knn = O.mutual_knn_pairs_np(fx["features"], coords, offsets, int(fx["k"]), float(fx["min_sp"]))
+    assert np.array_equal(pairs, fx["pairs"])
+    have = set(map(tuple, pairs.tolist()))
+    assert all((j, i) in have for i, j in have)                           # both directions of every mutual pair

@@ -56,6 +56,8 @@ SIGNATURES = {
     "frl_mean_time_fwd": (c_int, [P, P, L, I, L, I, P]),
     "frl_add": (c_int, [P, P, F, P, L, I, P]),
     "frl_normalize_tiles": (c_int, [P, I, P, P, P, I, P, L, I, P]),
+    "frl_mutual_knn_max_points": (S, [I]),
+    "frl_mutual_knn": (c_int, [P, I, I, P, P, F, I, P, P, P]),
     "frl_host_parallel_copy": (c_int, [P, P, S, I]),
     "frl_normalize_chunk_tiles": (c_int, [P, I, I, I, I, I, P, I, I, P, P, I, P, P]),
     "frl_conv3x3_fwd": (c_int, [P, P, P, P, I, I, I, I, I, I, I, P, S, P]),

@@ -334,6 +334,28 @@ def vq_revive_dead_codes(codebook: torch.Tensor, window_counts: torch.Tensor, mi
     return revived
 
 
+@_timed("mutual_knn")
+def mutual_knn(features: torch.Tensor, patch_id: torch.Tensor, coords: torch.Tensor, k: int, pos_min_spatial: float):
+    """features [N, D] float32, patch_id [N] int32, coords [N, 2] float32 -> (knn_idx [N, k] int32, mutual [N, k] uint8)."""
+    n, d = features.shape
+    if features.dtype != torch.float32 or not features.is_contiguous():
+        raise ValueError("mutual_knn: features must be contiguous float32 [N, D]")
+    if patch_id.dtype != torch.int32 or patch_id.numel() != n or coords.dtype != torch.float32 or tuple(coords.shape) != (n, 2) \
+            or not coords.is_contiguous() or not patch_id.is_contiguous():
+        raise ValueError("mutual_knn: patch_id must be int32 [N], coords float32 [N, 2]")
+    if d % 16 or d > 256:
+        if d > 256:
+            raise ValueError("mutual_knn: at most 256 feature channels")
+        # zero columns add exactly nothing to a squared distance (and leave the summation order of the real ones untouched)
+        features = torch.nn.functional.pad(features, (0, (-d) % 16)).contiguous()
+        d = features.shape[1]
+    knn = torch.empty((n, k), dtype=torch.int32, device=features.device)
+    mutual = torch.empty((n, k), dtype=torch.uint8, device=features.device)
+    check(_lib.load().frl_mutual_knn(_p(features), n, d, _p(patch_id), _p(coords), float(pos_min_spatial), int(k), _p(knn), _p(mutual),
+                                     _stream()), "frl_mutual_knn")
+    return knn, mutual
+
+
 @_timed("normalize_tiles")
 def normalize_tiles(raw: torch.Tensor, table: torch.Tensor, valid: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.bfloat16,
                     out: Optional[torch.Tensor] = None, mask_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
