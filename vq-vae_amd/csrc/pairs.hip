@@ -19,7 +19,8 @@ __global__ __launch_bounds__(64 * KNN_WAVES) void knn_kernel(const float* __rest
                                                              int* __restrict__ knn_idx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pitch = D + 4, d4 = D >> 2;
+  constexpr int d4 = 4 * D4PT;                                                     // D / 4: the host dispatches on D = 16 * D4PT
+  const int pitch = D + 4;
   float* qall = reinterpret_cast<float*>(smem);
   float* tile = qall + (size_t)KNN_WAVES * D;
   float* dist = tile + (size_t)64 * pitch + (size_t)wave * N;
@@ -33,8 +34,9 @@ __global__ __launch_bounds__(64 * KNN_WAVES) void knn_kernel(const float* __rest
   const float inf = __builtin_inff();
   const f32x4* q4 = reinterpret_cast<const f32x4*>(q);
   const int ntiles = (N + 63) >> 6;
-  f32x4 pre[D4PT];
-  auto fetch = [&](int tix) {                                                    // piece p of the tile: row p / d4, float4 column p % d4
+  f32x4 preA[D4PT], preB[D4PT];                                                  // two tiles in flight: with the distance rows in LDS only
+                                                                                 // one wave per SIMD is resident, nobody else hides the latency
+  auto fetch = [&](f32x4 (&pre)[D4PT], int tix) {                                // piece p of the tile: row p / d4, float4 column p % d4
 #pragma unroll
     for (int u = 0; u < D4PT; ++u) {
       const int p = tid + 256 * u;
@@ -43,23 +45,20 @@ __global__ __launch_bounds__(64 * KNN_WAVES) void knn_kernel(const float* __rest
       pre[u] = *reinterpret_cast<const f32x4*>(feat + (size_t)row * D + 4 * (p % d4));
     }
   };
-  auto commit = [&]() {
+  auto step = [&](f32x4 (&pre)[D4PT], int tix) {
+    __syncthreads();                                                             // everyone is done with the previous tile (and q is written)
 #pragma unroll
     for (int u = 0; u < D4PT; ++u) {
       const int p = tid + 256 * u;
       *reinterpret_cast<f32x4*>(tile + (size_t)(p / d4) * pitch + 4 * (p % d4)) = pre[u];
     }
-  };
-  fetch(0);
-  for (int tix = 0; tix < ntiles; ++tix) {
-    __syncthreads();                                                             // everyone is done with the previous tile (and q is written)
-    commit();
     __syncthreads();
-    if (tix + 1 < ntiles) fetch(tix + 1);
+    if (tix + 2 < ntiles) fetch(pre, tix + 2);
     const int j = tix * 64 + lane;
     const f32x4* x4 = reinterpret_cast<const f32x4*>(tile + (size_t)lane * pitch);
     float s = 0.f;
-    for (int d = 0; d < d4; ++d) {
+#pragma unroll 8
+    for (int d = 0; d < d4; ++d) {                                               // several LDS reads in flight per wave
       const f32x4 a = q4[d], b = x4[d];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const float t = a[e] - b[e]; s = fmaf(t, t, s); }
@@ -72,14 +71,29 @@ __global__ __launch_bounds__(64 * KNN_WAVES) void knn_kernel(const float* __rest
       }
       dist[j] = s;
     }
+  };
+  fetch(preA, 0);
+  if (ntiles > 1) fetch(preB, 1);
+  for (int tix = 0; tix < ntiles; tix += 2) {
+    step(preA, tix);
+    if (tix + 1 < ntiles) step(preB, tix + 1);
   }
   __builtin_amdgcn_wave_barrier();
   for (int r = 0; r < k; ++r) {
     float best = inf;
     int bj = 0x7fffffff;
-    for (int j = lane; j < N; j += 64) {
+    int j = lane;
+    for (; j + 7 * 64 < N; j += 8 * 64) {                                        // eight LDS reads in flight, then the ordered compares
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = dist[j + 64 * u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (v[u] < best) { best = v[u]; bj = j + 64 * u; }                       // ascending j per lane: first index wins ties
+    }
+    for (; j < N; j += 64) {
       const float v = dist[j];
-      if (v < best) { best = v; bj = j; }                                        // ascending j per lane: first index wins ties
+      if (v < best) { best = v; bj = j; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
