@@ -79,9 +79,20 @@ __global__ __launch_bounds__(64 * KNN_WAVES) void knn_kernel(const float* __rest
     if (tix + 1 < ntiles) step(preB, tix + 1);
   }
   __builtin_amdgcn_wave_barrier();
-  for (int r = 0; r < k; ++r) {
-    float best = inf;
-    int bj = 0x7fffffff;
+  // ---- k selection rounds.  Lane l owns the entries j = l, l + 64, ...; its running minimum (lbest, lj) is found once.  A round
+  // takes the wave-wide arg-min by (distance, index), retires the winner, and only the winner's owner needs a new minimum -- which
+  // all 64 lanes look for together in that owner's entries (two LDS reads each instead of a full rescan by every lane).
+  auto wave_argmin = [&](float& v, int& jx) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(v, off, 64);
+      const int oj = __shfl_xor(jx, off, 64);
+      if (ov < v || (ov == v && oj < jx)) { v = ov; jx = oj; }
+    }
+  };
+  float lbest = inf;
+  int lj = 0x7fffffff;
+  {
     int j = lane;
     for (; j + 7 * 64 < N; j += 8 * 64) {                                        // eight LDS reads in flight, then the ordered compares
       float v[8];
@@ -89,22 +100,31 @@ __global__ __launch_bounds__(64 * KNN_WAVES) void knn_kernel(const float* __rest
       for (int u = 0; u < 8; ++u) v[u] = dist[j + 64 * u];
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (v[u] < best) { best = v[u]; bj = j + 64 * u; }                       // ascending j per lane: first index wins ties
+        if (v[u] < lbest) { lbest = v[u]; lj = j + 64 * u; }                     // ascending j per lane: first index wins ties
     }
     for (; j < N; j += 64) {
       const float v = dist[j];
-      if (v < best) { best = v; bj = j; }
+      if (v < lbest) { lbest = v; lj = j; }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const float ov = __shfl_xor(best, off, 64);
-      const int oj = __shfl_xor(bj, off, 64);
-      if (ov < best || (ov == best && oj < bj)) { best = ov; bj = oj; }
-    }
-    const bool found = best < inf;
+  }
+  for (int r = 0; r < k; ++r) {
+    float best = lbest;
+    int bj = lj;
+    wave_argmin(best, bj);
+    const bool found = best < inf;                                               // wave-uniform
     if (live && lane == 0) knn_idx[(size_t)i * k + r] = found ? bj : -1;
-    if (found && (bj & 63) == lane) dist[bj] = inf;                              // owner lane retires the winner
+    if (!found) continue;                                                        // nothing admissible is left: the remaining slots are -1 too
+    const int owner = bj & 63;
+    if (lane == owner) dist[bj] = inf;                                           // retire the winner
     __builtin_amdgcn_wave_barrier();
+    float cb = inf;
+    int cj = 0x7fffffff;
+    for (int j = owner + 64 * lane; j < N; j += 64 * 64) {                       // the owner's entries, spread over the wave
+      const float v = dist[j];
+      if (v < cb) { cb = v; cj = j; }
+    }
+    wave_argmin(cb, cj);
+    if (lane == owner) { lbest = cb; lj = cb < inf ? cj : 0x7fffffff; }
   }
 }
 
