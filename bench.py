@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- tiles/sec of the full VQ-VAE train step (encoder -> VQ -> decoders, fwd + bwd + AdamW) on MI355X.
 
-Contract: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run, one rank per GPU).
+Contract: python bench.py --gpus N --steps K --warmup W.  N > 1 runs one rank per GPU over RCCL: either the caller starts the ranks
+(python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...: WORLD_SIZE is set and must equal N) or, when WORLD_SIZE
+is unset, this process starts them itself as a child `torch.distributed.run` BEFORE touching the GPU and relays rank 0's JSON line.
 Prints ONE JSON line on rank 0: metric tiles/sec on BASELINE.json configs[1] (B=256 tiles of 5x32x32x64 per GPU, K=512,
 d=64, bf16 activations, float32 master weights), plus
   * "roofline": the dominant kernel's achieved rate, timed live with HIP events on the launch stream;
@@ -13,6 +15,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -46,7 +50,31 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; nccl == RCCL (the measured configuration), gloo only to rehearse the N>1 control flow")
     ap.add_argument("--torch-optimizer", action="store_true", help="A/B: clip_grad_norm_ + torch.optim.AdamW instead of the two HIP launches")
+    ap.add_argument("--phase-codebook", type=int, default=0, help="second codebook on z_phase (BASELINE configs[4])")
+    ap.add_argument("--extra", action="store_true",
+                    help="N=1 only: also time BASELINE configs[3] (K=8192, d=128), configs[4] at one GPU (T=10, 64x64, two codebooks of 1024) "
+                         "and the float32 parity mode of configs[1]; reported under \"extra\" (secondary lines, never `value`)")
     return ap.parse_args()
+
+
+def launch_ranks(args) -> int:
+    """--gpus N > 1 without a launcher: start N ranks as a child torch.distributed.run (this process has not touched the GPU and
+    never will), relay rank 0's JSON line, return the child's exit code."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        sys.stdout.write(proc.stdout)
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank run failed (exit code {proc.returncode})\n")
+        return proc.returncode or 1
+    print(lines[-1], flush=True)
+    return 0
 
 
 def conv_flops_per_tile(T, S, F, d, zp, hidden=128):
@@ -61,34 +89,96 @@ def conv_flops_per_tile(T, S, F, d, zp, hidden=128):
 
 
 def cpu_baseline(args):
-    """Oracle train step on the host cores (rank 0, N=1): bounded sample of the same workload."""
+    """Oracle train step on the host cores (rank 0, N=1): bounded sample of the same workload, protocol of BASELINE.md section 4
+    (batches of 1 and 8 tiles, 3 warm-up + 10 timed steps each, median), at the codebook of the measured configuration."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import frl_oracle as O
     cores = min(os.cpu_count() or 1, 16)      # the box's CPU share for one GPU; more threads only thrash on these small ops
     torch.set_num_threads(cores)
-    bs = 16                                    # bounded sample: ~10 s of host work (1 warm-up + 8 timed steps of 16 tiles)
     g = torch.Generator().manual_seed(0)
     from frl_hip.models import VQVAE
     m = VQVAE(in_features=args.features, codebook_size=args.codebook, emb_dim=args.emb_dim, type_encoder_dropout=0.0,
               phase_tcn_dropout=0.0)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     sd["quant.codebook"] = torch.randn(args.codebook, args.emb_dim, generator=g)
-    tr = O.OracleTrainer(sd, dict(beta=0.25), lr=1e-4, total_steps=100)
-    tiles = [torch.randn(bs, args.time, args.size, args.size, args.features, generator=g) for _ in range(2)]
-    tr.step(tiles[0])
+    rates, total = {}, 0.0
+    for bs in (1, 8):
+        tr = O.OracleTrainer(sd, dict(beta=0.25), lr=1e-4, total_steps=100)
+        tiles = [torch.randn(bs, args.time, args.size, args.size, args.features, generator=torch.Generator().manual_seed(1234 + i))
+                 for i in range(2)]
+        for i in range(3):
+            tr.step(tiles[i % 2])
+        ts = []
+        for i in range(10):
+            t0 = time.perf_counter()
+            tr.step(tiles[i % 2])
+            ts.append(time.perf_counter() - t0)
+        total += sum(ts)
+        rates[bs] = bs / sorted(ts)[len(ts) // 2]
+    return {"value": round(rates[8], 2), "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"BASELINE.md section 4 protocol at this run's codebook: oracle train steps (reference encoder math + oracle VQ / decoder, "
+                      f"f32 torch CPU, float64 argmin, K={args.codebook}, d={args.emb_dim}), 3 warm-up + 10 timed steps per batch size, "
+                      f"median; value = batches of 8 tiles, batches of 1 tile: {rates[1]:.2f} tiles/s; {total:.1f} s timed"}
+
+
+def build_trainer(args, dev, dtype, codebook, emb_dim, phase_codebook=0, serial=False):
+    from frl_hip.models import VQVAE
+    from frl_hip.training.trainer import VQVAETrainer
+    torch.manual_seed(0)
+    model = VQVAE(in_features=args.features, codebook_size=codebook, emb_dim=emb_dim, beta=0.25, phase_codebook_size=phase_codebook,
+                  type_encoder_dropout=0.0, phase_tcn_dropout=0.0, compute_dtype=dtype).to(dev)
+    with torch.no_grad():   # well-separated codebook so that all codes are used (SURVEY.md 8d)
+        model.quant.codebook.copy_(torch.randn(codebook, emb_dim, generator=torch.Generator().manual_seed(7)))
+        if phase_codebook:
+            model.quant_phase.codebook.copy_(torch.randn(phase_codebook, model.z_phase_dim, generator=torch.Generator().manual_seed(8)))
+    model.concurrent_phase = not serial
+    trainer = VQVAETrainer(model, lr=1e-4, total_steps=10000, check_finite=not args.no_finite_check, fused_optimizer=not args.torch_optimizer)
+    return model, trainer
+
+
+def timed_steps(trainer, stream, steps, warmup, barrier):
+    """W untimed + exactly K timed steps bracketed by barrier + synchronize; returns (seconds, host seconds to queue the K steps, last out)."""
+    for _ in range(warmup):
+        trainer.step(stream.next())
+    barrier()
     t0 = time.perf_counter()
-    n = 8
-    for i in range(n):
-        tr.step(tiles[i % 2])
-    dt = time.perf_counter() - t0
-    return {"value": round(bs * n / dt, 2), "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"{n} timed oracle train steps of {bs} tiles (K={args.codebook}, d={args.emb_dim}, f32 torch CPU, "
-                      f"float64 argmin), {dt:.1f} s"}
+    last = None
+    for _ in range(steps):                            # timed region: exactly K steps, no instrumentation
+        last = trainer.step(stream.next())
+    t_host = time.perf_counter() - t0                 # the host has queued everything; the device may still be running
+    barrier()
+    return time.perf_counter() - t0, t_host, last
+
+
+def extra_lines(args, dev, barrier):
+    """Secondary single-GPU lines (never `value`): BASELINE configs[3], configs[4] at one GPU, and configs[1] in float32 parity mode."""
+    from frl_hip.data import SyntheticTileStream
+    out = {}
+    cases = [("configs[3]: K=8192 d=128, 256 tiles 5x32x32x64, bf16", dict(dtype=torch.bfloat16, K=8192, d=128, pK=0, B=256, T=5, S=32)),
+             ("configs[4] at 1 GPU: T=10, 64x64 tiles, type + phase codebooks of 1024, 32 tiles, bf16",
+              dict(dtype=torch.bfloat16, K=1024, d=64, pK=1024, B=32, T=10, S=64)),
+             ("configs[1] in float32 parity mode (the mode that meets 1e-5): K=512 d=64, 256 tiles 5x32x32x64",
+              dict(dtype=torch.float32, K=512, d=64, pK=0, B=256, T=5, S=32))]
+    for name, c in cases:
+        model, trainer = build_trainer(args, dev, c["dtype"], c["K"], c["d"], c["pK"])
+        stream = SyntheticTileStream(c["B"], c["T"], c["S"], args.features, device=dev, dtype=c["dtype"], seed=1234)
+        dt, th, last = timed_steps(trainer, stream, 10, 3, barrier)
+        out[name] = {"tiles/s": round(c["B"] * 10 / dt, 1), "ms_per_step": round(1e2 * dt, 3), "host_ms_per_step": round(1e2 * th, 3),
+                     "steps": 10, "warmup": 3, "loss": round(float(last["loss"].detach()), 5)}
+        del model, trainer, stream, last
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:            # nobody started the ranks: do it here, before anything touches the GPU
+        raise SystemExit(launch_ranks(args))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start exactly --gpus ranks "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -104,17 +194,9 @@ def main():
             dist.init_process_group("gloo")
     from frl_hip import ops
     from frl_hip.data import SyntheticTileStream
-    from frl_hip.models import VQVAE
-    from frl_hip.training.trainer import VQVAETrainer
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    torch.manual_seed(0)
-    model = VQVAE(in_features=args.features, codebook_size=args.codebook, emb_dim=args.emb_dim, beta=0.25,
-                  type_encoder_dropout=0.0, phase_tcn_dropout=0.0, compute_dtype=dtype).to(dev)
-    with torch.no_grad():   # well-separated codebook so that all codes are used
-        model.quant.codebook.copy_(torch.randn(args.codebook, args.emb_dim, generator=torch.Generator().manual_seed(7)))
-    model.concurrent_phase = not args.serial_streams
-    trainer = VQVAETrainer(model, lr=1e-4, total_steps=10000, check_finite=not args.no_finite_check, fused_optimizer=not args.torch_optimizer)
+    model, trainer = build_trainer(args, dev, dtype, args.codebook, args.emb_dim, args.phase_codebook, args.serial_streams)
     stream = SyntheticTileStream(args.batch, args.time, args.size, args.features, device=dev, dtype=dtype, seed=1234 + rank)
 
     def barrier():
@@ -123,16 +205,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        trainer.step(stream.next())
     timing = (not args.no_kernel_timing) and rank == 0
-    barrier()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):                       # timed region: exactly K steps, no instrumentation
-        last = trainer.step(stream.next())
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, t_host, last = timed_steps(trainer, stream, args.steps, args.warmup, barrier)
     ksum, ksteps = {}, 0
     if not args.no_kernel_timing:                     # separate instrumented steps: HIP events around every C-ABI call (rank 0)
         ksteps = max(2, min(5, args.steps))           # EVERY rank runs them: a step contains collectives
@@ -146,10 +220,17 @@ def main():
             ops.set_timing(False)
     if world > 1:
         barrier()
+    rank_ms = [1e3 * dt / args.steps]
+    rccl_ranks = 1
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        if args.backend == "gloo":
+            t = t.cpu()
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_ms = [1e3 * float(x.item()) / args.steps for x in allt]
+        dt = max(float(x.item()) for x in allt)       # MAX over ranks
+        rccl_ranks = dist.get_world_size()            # as seen inside the process group the gradients are reduced in
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -165,6 +246,9 @@ def main():
                                f"K={args.codebook}, d={args.emb_dim}, dropout 0.0",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}", "finite_check": not args.no_finite_check,
                    "loss": round(float(last["loss"].detach()), 5), "perplexity": round(float(last["perplexity"]), 2)},
+        "host_ms_per_step": round(1e3 * t_host / args.steps, 3),
+        "rank_ms_per_step": {"max": round(max(rank_ms), 3), "min": round(min(rank_ms), 3)},
+        "backend": ("rccl" if args.backend == "nccl" else "gloo") if world > 1 else None, "rccl_ranks": rccl_ranks,
     }
     if ksum:
         args.steps_timed, args.steps = args.steps, ksteps           # per-step normalisation of the instrumented steps
@@ -176,7 +260,7 @@ def main():
         vq_bytes = n * (2 * args.emb_dim * s + 4) + args.codebook * args.emb_dim * 4
         out["vq_hbm"] = {"GB/s": round(vq_bytes / vq_ms / 1e6, 1), "frac": round(vq_bytes / vq_ms / 1e6 / HBM_PEAK_GBS, 4),
                          "ms": round(vq_ms, 4), "bytes": vq_bytes,
-                         "note": "live HIP-event span of the whole frl_vq_assign_fwd call = prep + pack + assign + float64 fix-up + reductions"}
+                         "note": "live HIP-event span of the whole frl_vq_assign_fwd call (every kernel the call launches)"}
         ku = profiled_kernel_us("vq_assign_kernel")
         if ku is not None:                                    # the L2/argmin kernel alone, from the committed rocprofv3 kernel trace
             out["vq_hbm"]["assign_kernel_rocprof"] = {"us": ku[0], "GB/s": round(vq_bytes / ku[0] / 1e3, 1),
@@ -188,6 +272,9 @@ def main():
         out["conv_mfma"] = {"TFLOP/s": round(flops / conv_ms / 1e9, 1), "frac": round(flops / conv_ms / 1e9 / MFMA_BF16_PEAK_TF, 4),
                             "ms_per_step": round(conv_ms, 3), "GFLOP_per_step": round(flops / 1e9, 1),
                             "note": "algorithmic 3x-forward dense FLOPs / HIP-event time of all conv + TCN ops"}
+        mu = mfma_util_from_profiles()
+        if mu:
+            out["conv_mfma"]["mfma_util"] = mu
         # --- dominant kernel -> headline roofline object
         # dominant kernel FAMILY among those with a per-launch work model below (the fused TCN kernels at the measured configuration)
         modelled = ("tcn_block_bwd.main", "tcn_block_fwd", "vq_assign", "edge_smooth_fwd", "edge_smooth_bwd")
@@ -195,11 +282,25 @@ def main():
         dom = max(cands, key=lambda k: ksum[k][1])
         out["roofline"] = roofline_for(dom, ksum, args, model, n, s)
         args.steps = args.steps_timed
+    if world == 1 and args.extra:
+        del trainer, stream, last
+        out["extra"] = extra_lines(args, dev, barrier)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def mfma_util_from_profiles():
+    """MFMA busy fraction per conv kernel family from the newest committed SQ counter pass (profiles/*_mfma_util.json), or None."""
+    try:
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mfma_util.json")))[-1]
+        d = json.load(open(f))
+        return {"source": os.path.relpath(f, ROOT), **d.get("kernels", {})}
+    except Exception:
+        return None
 
 
 def profiled_kernel_us(substr):

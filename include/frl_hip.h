@@ -134,6 +134,10 @@ int frl_tcn_hot_bwd(const void* x, const void* drop_mask, const void* dy, const 
                     const float* gn_b, const float* gate_w, const float* gate_b, void* dx, float* d_conv_w, float* d_conv_b,
                     float* d_gn_w, float* d_gn_b, float* d_gate_w, float* d_gate_b, int64_t npix, int HW, int dilation,
                     float eps, void* ws, size_t ws_bytes, frl_stream_t stream);
+/* Two kernels stand behind frl_tcn_hot_bwd: tcn_hot_bwd3 (no mask, HW a multiple of 64: x of a 64-pixel tile is staged once in LDS by
+ * LDS-DMA, next tile prefetched) and the 8-wave kernel that also takes a mask and ragged pixel counts.  Test hook: on != 0 routes
+ * every call through the latter so that the two can be compared on the same inputs. */
+void frl_tcn_hot_force_generic_tiles(int on);
 
 /* ---- optimizer step (frl/training/representation/step.py:1081-1087: clip_grad_norm_(1.0) then AdamW.step()) ---------------
  * Two launches for the whole parameter set.  desc: HOST table of ntensors records {float* p; const float* g; float* m; float* v;

@@ -257,7 +257,8 @@ def test_tcn_block_bwd_fused_matches_oracle_and_unfused(B, T, HW, dil):
         assert rel_err(fused[kk].reshape(ref.shape), unf[kk].reshape(ref.shape).cpu()) <= 0.03, kk
 
 
-@pytest.mark.parametrize("B,HW,dil", [(1, 1024, 1), (2, 1024, 2), (3, 100, 4), (1, 77, 2), (5, 13, 1), (1, 16, 4)])
+@pytest.mark.parametrize("B,HW,dil", [(1, 1024, 1), (2, 1024, 2), (3, 100, 4), (1, 77, 2), (5, 13, 1), (1, 16, 4), (3, 64, 4), (2, 4096, 1),
+                                      (3, 1024, 4)])
 def test_tcn_hot_kernels_match_oracle_and_generic(B, HW, dil):
     """The (T=5, dilation)-specialised bf16 block kernels vs float64 autograd and vs the generic kernels (ragged pixel counts too)."""
     from frl_hip import ops, _lib
@@ -290,6 +291,37 @@ def test_tcn_hot_kernels_match_oracle_and_generic(B, HW, dil):
         ref = ref_st[p + nm].grad
         assert rel_err(hot[kk].reshape(ref.shape), ref) <= 2e-2, kk
         assert rel_err(hot[kk].reshape(ref.shape), gen[kk].reshape(ref.shape).cpu()) <= 2e-2, kk
+
+
+@pytest.mark.parametrize("B,HW,dil", [(21, 1024, 1), (18, 1024, 2), (5, 4096, 4), (600, 64, 1)])
+def test_tcn_hot_bwd_staged_tiles_match_the_8_wave_kernel(B, HW, dil):
+    """frl_tcn_hot_bwd has two kernels (include/frl_hip.h): the LDS-staged one (no mask, HW % 64 == 0) must agree with the 8-wave kernel
+    on the same inputs to bf16 rounding of dx and to float32 summation order of the parameter gradients -- with MORE 64-pixel tiles
+    than workgroups (256), so that every workgroup walks several tiles (next-tile LDS-DMA, X / N buffer swap) -- and twice in a row
+    bit for bit (fixed-order reductions)."""
+    from frl_hip import ops, _lib
+    dtype, cin, cout, G, T = torch.bfloat16, 64, 64, 8, 5
+    assert B * HW // 64 > 256
+    g = torch.Generator().manual_seed(B * HW + dil)
+    w = dict(conv_w=torch.randn(cout, cin, 3, generator=g) / (3 * cin) ** 0.5, conv_b=torch.randn(cout, generator=g) * 0.1,
+             gn_w=torch.rand(cout, generator=g) + 0.5, gn_b=torch.randn(cout, generator=g) * 0.2,
+             gate_w=torch.randn(cout, cout, 1, generator=g) / cout ** 0.5, gate_b=torch.randn(cout, generator=g) * 0.1)
+    args = tuple(w[k].to(DEV) for k in ("conv_w", "conv_b", "gn_w", "gn_b", "gate_w", "gate_b")) + (None, None)
+    xd = torch.randn(B, T, HW, cin, generator=g).to(dtype).to(DEV)
+    dyd = torch.randn(B, T, HW, cout, generator=g).to(dtype).to(DEV)
+    new = ops.tcn_block_bwd(xd, dyd, *args, dil, G)
+    again = ops.tcn_block_bwd(xd, dyd, *args, dil, G)
+    lib = _lib.load()
+    lib.frl_tcn_hot_force_generic_tiles(1)
+    try:
+        old = ops.tcn_block_bwd(xd, dyd, *args, dil, G)
+    finally:
+        lib.frl_tcn_hot_force_generic_tiles(0)
+    for k in new:
+        assert torch.equal(new[k], again[k]), k
+    assert rel_err(new["dx"].float().cpu(), old["dx"].float().cpu()) <= 6e-3        # both round dx (and dres inside) to bf16
+    for k in ("conv_w", "conv_b", "gn_w", "gn_b", "gate_w", "gate_b"):
+        assert rel_err(new[k].cpu(), old[k].cpu()) <= 2e-3, k
 
 
 @pytest.mark.parametrize("B,HW,dil,p", [(2, 1024, 1, 0.5), (3, 100, 4, 0.25), (1, 77, 2, 0.1)])

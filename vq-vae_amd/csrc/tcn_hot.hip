@@ -12,11 +12,8 @@
 //             the phase structure is described above the kernel).  Wave (q, h) owns rows [16q, 16q+16) x columns [32h, 32h+32) of the
 //             four 64x64 gradient matrices in registers for the whole kernel; per-workgroup float32 slabs are summed in a fixed order
 //             afterwards (bit-reproducible, no float atomics).
-#include "tcn_common.hpp"
-#include "frl_host.hpp"
-#include "frl_reduce.hpp"
+#include "tcn_hot_common.hpp"
 
-#define TH_T 5
 // Diagnostic build only (tools/diag/tcn_bwd_stamps.hip defines TH_STAMPS): s_memtime stamps at the phase boundaries of the
 // backward kernel, accumulated in LDS and written to a buffer nothing else reads.  The product library never defines it.
 #ifdef TH_STAMPS
@@ -24,12 +21,7 @@ __device__ unsigned long long* th_dbg;
 #endif
 #define TH_PITCH 72       // bf16 elements per pixel row in LDS tiles (64 + 8: conflict-free 16-byte writes and tr16 reads)
 
-typedef bf16x8 frag8;
 struct Tile2 { frag8 f[2]; };
-
-template <int DIL> __device__ __forceinline__ constexpr bool th_valid(int t, int k) {
-  return t + (k - 1) * DIL >= 0 && t + (k - 1) * DIL < TH_T;
-}
 
 __device__ __forceinline__ float th_elem(const Tile2& t, int j) { return (float)t.f[j >> 3][j & 7]; }
 
@@ -208,8 +200,6 @@ __device__ __forceinline__ void th_put(bf16* tile, int prow, int kc, const Tile2
   p[1] = t.f[1];
 }
 
-// slab layout per workgroup (floats): [3][64][64] conv taps | [64][64] gate | [64] dbc | [64] dbg | [64] dgamma | [64] dbeta
-#define TH_SLAB (4 * 64 * 64 + 4 * 64)
 #define TH_TILE (64 * TH_PITCH)
 
 // =============================================================================================================
@@ -225,12 +215,6 @@ __device__ __forceinline__ void th_put(bf16* tile, int prow, int kc, const Tile2
 //   P3  publish dconv[t], x[t]                                                                     | barrier D
 //   dx = conv^T(dconv) + dres (stored);  P4 conv weight gradients                                  | barrier E
 // =============================================================================================================
-__device__ __forceinline__ frag8 th_pack8(const float (&v)[8]) {
-  frag8 o;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
-  return o;
-}
 __device__ __forceinline__ Tile2 th_get(const bf16* tile, int prow, int kc) {
   const frag8* p = reinterpret_cast<const frag8*>(tile + prow * TH_PITCH + 16 * kc);
   Tile2 t;
@@ -615,19 +599,12 @@ struct ThEpi {
   }
 };
 
-static unsigned th_bwd_grid(int64_t npix) {
-  int64_t g = (npix + 63) / 64;
-  if (g > 256) g = 256;
-  if (g < 1) g = 1;
-  return (unsigned)g;
-}
 static unsigned th_fwd_grid(int64_t npix) {
   int64_t g = ((npix + 15) / 16 + 3) / 4;
   if (g > 512) g = 512;
   if (g < 1) g = 1;
   return (unsigned)g;
 }
-static constexpr size_t TH_PACK_BYTES = (size_t)64 * 64 * sizeof(frag8);
 static constexpr size_t TH_FWD_LDS = (size_t)32 * 64 * sizeof(frag8) + 4 * 64 * sizeof(float);
 static constexpr size_t TH_BWD_LDS = TH_PACK_BYTES + (size_t)(4 * 64 + 4 * 2 * 64) * sizeof(float) + (size_t)2 * TH_T * TH_TILE * sizeof(bf16);
 
@@ -660,7 +637,12 @@ static int th_launch_bwd(const void* x, const void* mask, const void* dy, const 
   return 0;
 }
 
+static int g_th_force_bwd2 = 0;
+
 extern "C" {
+
+// test hook: 1 routes every hot backward through the 8-wave kernel of this file (mask / ragged-tile path), 0 restores the dispatch
+void frl_tcn_hot_force_generic_tiles(int on) { g_th_force_bwd2 = on; }
 
 // 1 when the specialised kernels apply: bf16, 64 -> 64 channels, T = 5, 8 groups, identity residual, dilation 1 / 2 / 4
 int frl_tcn_hot_supported(int T, int Cin, int Cout, int G, int dilation, int has_proj, int dtype) {
@@ -701,7 +683,9 @@ int frl_tcn_hot_bwd(const void* x, const void* drop_mask, const void* dy, const 
   frag8* pk = reinterpret_cast<frag8*>(reinterpret_cast<char*>(ws) + (((size_t)grid * TH_SLAB * sizeof(float) + 255) / 256) * 256);
   FRL_LAUNCH(tcn_hot_pack_kernel, dim3(32), dim3(256), 0, stream, pk, conv_w, gate_w);
   int rc = -2;
-  if (dilation == 1) rc = th_launch_bwd<1>(x, drop_mask, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
+  if (drop_mask == nullptr && th_bwd3_supported(npix, HW) && !g_th_force_bwd2)      // the measured configuration: tcn_hot_bwd3.hip
+    rc = th_bwd3_launch(dilation, x, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
+  else if (dilation == 1) rc = th_launch_bwd<1>(x, drop_mask, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
   else if (dilation == 2) rc = th_launch_bwd<2>(x, drop_mask, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
   else if (dilation == 4) rc = th_launch_bwd<4>(x, drop_mask, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
   else return frl_fail(-2, "tcn_hot_bwd: dilation must be 1, 2 or 4");

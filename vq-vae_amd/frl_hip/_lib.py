@@ -82,6 +82,7 @@ SIGNATURES = {
     "frl_tcn_hot_bwd_workspace_bytes": (S, [L]),
     "frl_tcn_hot_fwd": (c_int, [P, P, P, P, P, P, P, P, P, L, I, I, F, P, S, P]),
     "frl_tcn_hot_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, F, P, S, P]),
+    "frl_tcn_hot_force_generic_tiles": (None, [I]),
     "frl_tcn_block_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, F, I, P, S, P]),
 }
 
