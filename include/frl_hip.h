@@ -33,6 +33,10 @@ enum { FRL_ACT_NONE = 0, FRL_ACT_RELU = 1, FRL_ACT_SIGMOID = 2 };
 int frl_version(void);
 const char* frl_last_error(void);
 int frl_device_arch(char* buf, int n); /* must report gfx950 */
+/* Live per-kernel timing (bench.py): with the switch on, every kernel the library launches is bracketed by a HIP event pair recorded on
+ * its launch stream; the report synchronises them and writes "kernel expression \t calls \t total ms \n" lines. */
+int frl_kernel_timing_enable(int on);
+int frl_kernel_timing_report(char* buf, int n);
 
 /* ---- pointwise (1x1) convolution --------------------------------------------------------------------------------
  * nn.Conv2d(.,.,1): frl/models/conv2d_encoder.py:106-114; spatial.py:262-263; representation.py:169;
@@ -137,7 +141,7 @@ int frl_tcn_hot_bwd(const void* x, const void* drop_mask, const void* dy, const 
 /* Two kernels stand behind frl_tcn_hot_bwd: tcn_hot_bwd3 (no mask, HW a multiple of 64: x of a 64-pixel tile is staged once in LDS by
  * LDS-DMA, next tile prefetched) and the 8-wave kernel that also takes a mask and ragged pixel counts.  Test hook: on != 0 routes
  * every call through the latter so that the two can be compared on the same inputs. */
-void frl_tcn_hot_force_generic_tiles(int on);
+int frl_tcn_hot_force_generic_tiles(int on);   /* returns the previous setting */
 
 /* ---- optimizer step (frl/training/representation/step.py:1081-1087: clip_grad_norm_(1.0) then AdamW.step()) ---------------
  * Two launches for the whole parameter set.  desc: HOST table of ntensors records {float* p; const float* g; float* m; float* v;
@@ -221,8 +225,10 @@ int frl_vq_assign_fwd(const void* z, const float* E, int64_t N, int K, int d, in
 int frl_vq_bwd(const void* g_out, const void* z, const void* zq /* optional */, const float* E, const int32_t* idx, const int32_t* counts,
                const float* gscale, float beta, int64_t N, int K, int d, void* g_z_out, float* g_E_out, float* sums_out,
                int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
+/* ok: NULL, or a device float -- ok[0] <= 0 (or NaN) skips the update on the device (the train step's isfinite guard, evaluated
+ * without a host synchronisation; frl/training/representation/step.py:1057-1074 "skip the batch"). */
 int frl_vq_ema_update(const float* sums, const int32_t* counts, int K, int d, float decay, float eps, float* ema_count,
-                      float* ema_sum, float* E, frl_stream_t stream);
+                      float* ema_sum, float* E, const float* ok, frl_stream_t stream);
 /* Dead-code revival of the legacy trainer's CodebookManager (scripts/train_vqvae.py:92,196-198 constructs and attaches it; the
  * module is not in the reference tree -- build definition): codes with window_counts[k] < min_count are re-seeded with the
  * encoder row z[splitmix64(seed + k) mod N], their AdamW moment rows m / v (optional) are cleared, *revived += number of codes. */

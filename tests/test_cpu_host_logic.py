@@ -250,3 +250,99 @@ def test_denormalize_inverts_the_ingest_normalisation():
     assert mask.all()
     back = denormalize(normed, [NormPreset.from_dict(p) for p in presets], stats)
     assert np.abs(back - raw).max() < 1e-5
+
+
+def test_legacy_trainer_script_calls_work_verbatim():
+    """The statements of scripts/train_vqvae.py:153-198,221-224 that touch the dataset and the model, run as written against the
+    build's classes: chunk sampler from ds.xy_by_chunk, cat_vocab_sizes / naip_bands / cont_dim from the dataset attributes, the VQVAE
+    constructor call with the legacy keyword set, CodebookManager(num_codes=model.quant.codebook_size, ...), the two optimizer groups."""
+    from frl_hip.data import ChunkBatchSampler, ForestDataset
+    from frl_hip.models import VQVAE
+    from frl_hip.training.codebook_manager import CodebookManager
+    ds = ForestDataset(num_tiles=40, features=8, size=8, tiles_per_chunk=16)
+    batch_sampler = ChunkBatchSampler(ds.xy_by_chunk, batch_size=8, drop_last=False, replacement_within_chunk=False, seed=42)
+    assert sum(len(b) for b in batch_sampler) == 40
+    cat_vocab_sizes = {}
+    for name in ds.cat_names:
+        entry = ds.schema_cat.get(name)
+        if entry is not None:
+            cat_vocab_sizes[name] = int(entry["num_ids"])
+    naip_bands = int(ds.naip.shape[-1])
+    cont_dim = len(ds.cont_names)
+    assert (cat_vocab_sizes, naip_bands, cont_dim) == ({}, 0, 8)
+    model = VQVAE(cont_dim=cont_dim, cat_vocab_sizes=cat_vocab_sizes, naip_bands=naip_bands, emb_dim=8, codebook_size=16, beta=0.25,
+                  hidden=16, quantizer="st", cat_emb_dim=8, ema_decay=0.99, ema_eps=1e-5,
+                  type_encoder_channels=(16, 8), type_encoder_num_groups=4, spatial_conv_gate_hidden=8, phase_tcn_channels=(8, 8, 8),
+                  phase_tcn_num_groups=4, z_phase_dim=4)
+    assert model.in_features == 8 and model.cont_dim == 8 and model.legacy_inputs["naip_bands"] == 0
+    manager = CodebookManager(num_codes=model.quant.codebook_size, code_dim=model.quant.emb_dim)
+    model.attach_codebook_manager(manager)
+    codebook_params = [p for n, p in model.named_parameters() if ".quant.codebook" in n or n.endswith("quant.codebook")]
+    other_params = [p for n, p in model.named_parameters() if (".quant.codebook" not in n and not n.endswith("quant.codebook"))]
+    assert len(codebook_params) == 1 and codebook_params[0] is model.quant.codebook and len(other_params) > 10
+    class_weights = {name: ds.class_weights_by_cat_name(name) for name in ds.cat_names}
+    assert class_weights == {}
+    with pytest.raises(ValueError, match="cat_vocab_sizes"):
+        VQVAE(cont_dim=8, cat_vocab_sizes={"evt": 12}, naip_bands=4, emb_dim=8)
+    with pytest.raises(ValueError, match="disagree"):
+        VQVAE(cont_dim=8, in_features=16, emb_dim=8)
+    with pytest.raises(KeyError):
+        ds.class_weights_by_cat_name("evt")
+
+
+def test_lambda_vq_schedule_flags():
+    """`--anneal_vq_*` flags of scripts/train_vqvae.py:433-456 (build definition of the curves: training/schedules.py)."""
+    from frl_hip.training.schedules import build_lambda_vq
+    off = build_lambda_vq(0.7, {})
+    assert [off(s) for s in (0, 10, 10**6)] == [0.7, 0.7, 0.7]
+    # the script's defaults once enabled: warm-up 10000 to ceil 0.1, hold 15000, decay 5000 to final 0.08
+    d = build_lambda_vq(1.0, dict(anneal_vq_enable=True, anneal_vq_schedule="warmup_hold_decay", anneal_vq_start=0, anneal_vq_floor=0.0,
+                                  anneal_vq_ceil=0.1, anneal_vq_warmup=10000, anneal_vq_hold=15000, anneal_vq_decay=5000,
+                                  anneal_vq_final=0.08))
+    assert d(0) == 0.0 and abs(d(5000) - 0.05) < 1e-15 and d(10000) == 0.1 and d(24999) == 0.1
+    assert abs(d(27500) - 0.09) < 1e-15 and d(30000) == 0.08 and d(10**7) == 0.08
+    lin = build_lambda_vq(2.0, dict(anneal_vq_enable=True, anneal_vq_schedule="linear", anneal_vq_start=100, anneal_vq_duration=100,
+                                    anneal_vq_floor=0.5, anneal_vq_ceil=None))
+    assert lin(0) == 0.5 and lin(100) == 0.5 and lin(150) == 1.25 and lin(200) == 2.0 and lin(999) == 2.0        # ceil None -> lambda_vq
+    cos = build_lambda_vq(1.0, dict(anneal_vq_enable=True, anneal_vq_schedule="cosine", anneal_vq_duration=10, anneal_vq_ceil=1.0))
+    assert cos(0) == 0.0 and abs(cos(5) - 0.5) < 1e-15 and cos(10) == 1.0 and cos(2) < 0.2 * 1.0
+    ex = build_lambda_vq(1.0, dict(anneal_vq_enable=True, anneal_vq_schedule="exponential", anneal_vq_duration=10, anneal_vq_ceil=1.0, anneal_vq_k=5.0))
+    assert ex(0) == 0.0 and ex(10) == 1.0 and ex(5) > 0.9
+    st = build_lambda_vq(1.0, dict(anneal_vq_enable=True, anneal_vq_schedule="stepwise", anneal_vq_floor=0.0,
+                                   anneal_vq_milestones=["8000:0.1", "1000:0.01"]))
+    assert [st(s) for s in (0, 999, 1000, 7999, 8000, 10**6)] == [0.0, 0.0, 0.01, 0.01, 0.1, 0.1]
+    const = build_lambda_vq(1.0, dict(anneal_vq_enable=True, anneal_vq_schedule="constant", anneal_vq_start=5, anneal_vq_ceil=0.3, anneal_vq_floor=0.1))
+    assert const(4) == 0.1 and const(5) == 0.3
+    with pytest.raises(ValueError):
+        build_lambda_vq(1.0, dict(anneal_vq_enable=True, anneal_vq_schedule="sawtooth"))
+
+
+def test_build_trainer_from_vae_config(tmp_path):
+    """configs/vae_v0.yaml gets the consumer the reference lacks: model, optimizer groups, cosine LR over T_max_epochs, beta ramp,
+    lambda_vq(step) and the checkpoint directory all come from the file."""
+    import yaml
+    from frl_hip.config import build_trainer_from_config, load_vae_config
+    raw = yaml.safe_load(open(os.path.join(ROOT, "configs", "vae_v0.yaml")))
+    raw.update(codebook_size=16, emb_dim=8, hidden=16, run_root=str(tmp_path), lambda_vq=0.5, anneal_vq_enable=True, anneal_vq_schedule="linear",
+               anneal_vq_duration=10, anneal_vq_ceil=None, clip_grad=0.5)
+    raw["beta_schedule"] = dict(enabled=True, schedule_type="linear", start_epoch=0, end_epoch=10, start_value=0.1, end_value=1.0)
+    raw["optimizer"]["scheduler"] = dict(name="cosine", T_max_epochs=2, eta_min=1e-6)
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(raw))
+    cfg = load_vae_config(str(path))
+    assert cfg.hidden == 16 and cfg.anneal_vq["anneal_vq_schedule"] == "linear" and cfg.clip_grad == 0.5
+    model, trainer, ckpt, run_dir = build_trainer_from_config(
+        cfg, steps_per_epoch=5, in_features=8,
+        model_kwargs=dict(type_encoder_channels=(16, 8), type_encoder_num_groups=4, spatial_conv_gate_hidden=8, phase_tcn_channels=(8, 8, 8),
+                          phase_tcn_num_groups=4, z_phase_dim=4))
+    assert model.quant.codebook_size == 16 and model.quant.emb_dim == 8 and model.decoder_type.layers[0].out_channels == 16
+    assert trainer.total_steps == 10 and trainer.lr == 1e-4 and trainer.min_lr == 1e-6 and trainer.max_norm == 0.5
+    groups = trainer.opt.param_groups
+    assert len(groups) == 2 and groups[0]["weight_decay"] == 0.01 and groups[1]["weight_decay"] == 0.0 and groups[0]["betas"] == (0.9, 0.95)
+    assert len(groups[1]["params"]) == 1 and groups[1]["params"][0] is model.quant.codebook
+    assert model.quant.beta == 0.1                                   # beta_schedule at epoch 0
+    trainer.set_epoch(5)
+    assert abs(model.quant.beta - 0.55) < 1e-12
+    assert trainer.lambda_vq_schedule(0) == 0.0 and trainer.lambda_vq_schedule(10) == 0.5
+    assert run_dir == os.path.join(str(tmp_path), cfg.experiment_name) and os.path.isdir(os.path.join(run_dir, cfg.ckpt_dir))
+    assert ckpt.dir == __import__("pathlib").Path(run_dir) / cfg.ckpt_dir

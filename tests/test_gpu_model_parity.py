@@ -249,6 +249,77 @@ def test_ema_quantizer_updates_codebook():
     assert m.quant.codebook.grad is None
 
 
+def test_nonfinite_batch_leaves_ema_and_codebook_manager_untouched():
+    """The isfinite guard covers the state forward() would mutate: with quantizer='ema' and a CodebookManager attached, an Inf tile
+    must change neither the EMA running averages, the codebook, nor the manager's usage window, and its (non-finite) rows must never
+    seed a code -- step.py:1057-1074 skips the whole batch."""
+    from frl_hip.models import VQVAE
+    from frl_hip.training.codebook_manager import CodebookManager
+    from frl_hip.training.trainer import VQVAETrainer
+    torch.manual_seed(0)
+    m = VQVAE(in_features=8, codebook_size=16, emb_dim=8, hidden=16, quantizer="ema", z_phase_dim=4, type_encoder_channels=(16, 8),
+              type_encoder_dropout=0.0, type_encoder_num_groups=4, spatial_conv_gate_hidden=8, phase_tcn_channels=(8, 8, 8),
+              phase_tcn_dropout=0.0, phase_tcn_num_groups=4).to(DEV)
+    mgr = CodebookManager(num_codes=16, code_dim=8, reset_every=2, min_count=1)
+    m.attach_codebook_manager(mgr)
+    tr = VQVAETrainer(m, lr=1e-3, total_steps=10)
+    assert tr.hip_opt and m.defer_codebook_hooks and m.quant.defer_ema
+    g = torch.Generator().manual_seed(3)
+    good = [torch.randn(2, 5, 8, 8, 8, generator=g).to(DEV) for _ in range(3)]
+    cb0 = m.quant.codebook.detach().clone()
+    tr.step(good[0])
+    cb1, n1, s1 = m.quant.codebook.detach().clone(), m.quant.ema_count.clone(), m.quant.ema_sum.clone()
+    assert not torch.equal(cb0, cb1)                                  # the good batch did move the codebook
+    w1 = mgr.window.clone()
+    assert int(w1.sum()) == 2 * 8 * 8
+    bad = good[1].clone()
+    bad[0, 0, 0, 0, 0] = float("inf")
+    out = tr.step(bad)                                                # reset_every = 2: a revival pass runs right after this step
+    assert not torch.isfinite(out["loss"]).item()
+    assert torch.equal(m.quant.codebook.detach(), cb1) and torch.equal(m.quant.ema_count, n1) and torch.equal(m.quant.ema_sum, s1)
+    assert torch.isfinite(m.quant.codebook).all() and int(mgr.revived.item()) == 0 and int(mgr.window.sum()) == 0
+    assert tr.opt.applied_and_skipped == (1, 1)
+    out = tr.step(good[2])
+    assert torch.isfinite(out["loss"]).item() and torch.isfinite(m.quant.codebook).all()
+    assert not torch.equal(m.quant.codebook.detach(), cb1) and int(mgr.window.sum()) == 2 * 8 * 8
+
+
+def test_configs1_train_step_end_to_end():
+    """BASELINE configs[1] as bench.py measures it (256 tiles of 5x32x32x64, K = 512, d = 64, bf16): one full train step through the
+    HIP path -- VQ indices are the exact float64 argmin of the latents the encoder produced, every loss term is finite, parameters move."""
+    from frl_hip.models import VQVAE
+    from frl_hip.training.trainer import VQVAETrainer
+    torch.manual_seed(0)
+    m = VQVAE(in_features=64, codebook_size=512, emb_dim=64, beta=0.25, type_encoder_dropout=0.0, phase_tcn_dropout=0.0,
+              compute_dtype=torch.bfloat16).to(DEV)
+    with torch.no_grad():
+        m.quant.codebook.copy_(torch.randn(512, 64, generator=torch.Generator().manual_seed(7)))
+    tr = VQVAETrainer(m, lr=1e-4, total_steps=100)
+    tile = torch.randn(256, 5, 32, 32, 64, generator=torch.Generator().manual_seed(1234)).to(torch.bfloat16).to(DEV)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    e = m.quant.codebook.detach().cpu().to(torch.bfloat16).double().numpy()      # the kernel rounds the codebook to bf16 for the MFMA
+    out = tr.step(tile)
+    torch.cuda.synchronize()
+    for k in ("loss", "l_type", "l_phase", "vq_loss", "perplexity", "grad_norm"):
+        assert torch.isfinite(out[k]).all(), k
+    assert tr.opt.applied_and_skipped == (1, 0)
+    z = out["z_type"].detach().float().cpu().reshape(-1, 64).double().numpy()
+    idx = out["idx"].cpu().numpy().astype(np.int64)
+    assert idx.shape == (256 * 32 * 32,)
+    ref = np.empty_like(idx)
+    e2 = (e * e).sum(1)
+    for lo in range(0, z.shape[0], 32768):                                          # float64 brute force, first index on ties
+        zz = z[lo:lo + 32768]
+        ref[lo:lo + 32768] = np.argmin((zz * zz).sum(1)[:, None] - 2.0 * zz @ e.T + e2[None, :], axis=1)
+    bad = np.flatnonzero(ref != idx)
+    if bad.size:                                                                    # float64 ties of the expanded form: compare distances
+        d_ref = ((z[bad] - e[ref[bad]]) ** 2).sum(1)
+        d_got = ((z[bad] - e[idx[bad]]) ** 2).sum(1)
+        assert np.all(d_got <= d_ref + 1e-9 * np.maximum(1.0, d_ref)) and np.all((d_got < d_ref - 1e-12) | (idx[bad] <= ref[bad])), bad[:8]
+    moved = sum(int(not torch.equal(p.detach(), before[n])) for n, p in m.named_parameters())
+    assert moved == len(before)
+
+
 @pytest.mark.parametrize("name,kw,tile_shape", [
     # BASELINE configs[3]: large codebook K = 8192, d = 128 (encoder channels [128, 128])
     ("cfg4", dict(codebook_size=8192, emb_dim=128), (2, 5, 32, 32, 64)),

@@ -7,3 +7,5 @@ $CC -o tcn_bwd_v2.bin tcn_bwd_stamps.hip
 $CC -DTH_STAMPS -o tcn_bwd_v2_stamps.bin tcn_bwd_stamps.hip
 $CC -o vq_stamps.bin vq_stamps.hip
 $CC -o c3_stamps.bin c3_stamps.hip
+$CC -o tcn_bwd3.bin tcn_bwd3_stamps.hip
+$CC -DB3_STAMPS -o tcn_bwd3_stamps.bin tcn_bwd3_stamps.hip

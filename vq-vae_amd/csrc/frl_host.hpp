@@ -11,10 +11,20 @@ int frl_check_launch(const char* what);            // hipGetLastError() -> 0 or 
 // runtime initialisation done elsewhere in the process (e.g. by PyTorch), so the state is cleared before every launch
 // and the first failure of a call is parked in g_frl_pending until frl_check_launch() reports it.
 extern thread_local hipError_t g_frl_pending;
+// Optional per-kernel timing (frl_kernel_timing_enable): a HIP event pair recorded on the launch stream immediately around every
+// kernel the library launches, keyed by the kernel expression -- the live counterpart of a rocprofv3 kernel trace (bench.py).
+extern int g_frl_timing;
+void frl_timing_begin(const char* kernel, hipStream_t st);
+void frl_timing_end(hipStream_t st);
+#define FRL_ARG1_(a, ...) a
+#define FRL_ARG5_(a, b, c, d, e, ...) e
+#define FRL_STR_(...) #__VA_ARGS__
 #define FRL_LAUNCH(...)                                                     \
   do {                                                                      \
     (void)hipGetLastError();                                                \
+    if (g_frl_timing) frl_timing_begin(FRL_STR_(FRL_ARG1_(__VA_ARGS__)), FRL_ARG5_(__VA_ARGS__)); \
     hipLaunchKernelGGL(__VA_ARGS__);                                        \
+    if (g_frl_timing) frl_timing_end(FRL_ARG5_(__VA_ARGS__));               \
     hipError_t _le = hipGetLastError();                                     \
     if (_le != hipSuccess && g_frl_pending == hipSuccess) g_frl_pending = _le; \
   } while (0)

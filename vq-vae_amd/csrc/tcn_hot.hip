@@ -642,7 +642,7 @@ static int g_th_force_bwd2 = 0;
 extern "C" {
 
 // test hook: 1 routes every hot backward through the 8-wave kernel of this file (mask / ragged-tile path), 0 restores the dispatch
-void frl_tcn_hot_force_generic_tiles(int on) { g_th_force_bwd2 = on; }
+int frl_tcn_hot_force_generic_tiles(int on) { const int was = g_th_force_bwd2; g_th_force_bwd2 = on; return was; }
 
 // 1 when the specialised kernels apply: bf16, 64 -> 64 channels, T = 5, 8 groups, identity residual, dilation 1 / 2 / 4
 int frl_tcn_hot_supported(int T, int Cin, int Cout, int G, int dilation, int has_proj, int dtype) {

@@ -91,6 +91,15 @@ __device__ __forceinline__ float b3_row_sum(float v) {
 #define B3_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define B3_BARRIER_ALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// Diagnostic build only (tools/diag/tcn_bwd3_stamps.hip defines B3_STAMPS): s_memtime stamps at the phase boundaries, accumulated in the
+// spare LDS behind the d gamma / d beta slots and written to a buffer nothing else reads.  The product library never defines it.
+#ifdef B3_STAMPS
+__device__ unsigned long long* b3_dbg;
+#define B3_ST(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63u) == 0) b3_ts[wave * 12 + (i)] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define B3_ST(i) do { } while (0)
+#endif
+
 template <int DIL>
 __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __restrict__ X, const bf16* __restrict__ DY, const frag8* __restrict__ Wpk,
                                                               const float* __restrict__ bc, const float* __restrict__ gn_w,
@@ -130,20 +139,29 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __rest
     const unsigned b = (unsigned)wt / tps;                         // sample of the tile (tiles never straddle samples: HW % 64 == 0)
     return ((int64_t)wt * 64 + (int64_t)b * (TH_T - 1) * HW) * 64;
   };
-  // ---- DMA of one tile's x into a tile buffer: wave w issues pieces j = 5 w .. 5 w + 4 (1 KB = 8 pixel rows of one time step each)
+  // ---- DMA of one tile's x into a tile buffer: wave w issues pieces j = 5 w .. 5 w + 4 (1 KB = 8 pixel rows of one time step each).
+  // Issued through inline asm: hipcc orders every later LDS access behind a builtin LDS-DMA with s_waitcnt vmcnt(0) (it cannot know that
+  // the DMA targets another buffer), which parked all eight waves for a full HBM latency right after the issue.  Invisible to the
+  // compiler, the transfers stay in flight across the conv^T / weight-gradient phases; the E' barrier waits for them explicitly.
+  // (A hidden vector-memory operation only makes the compiler's own counted waits stricter, never looser: they count from the youngest.)
   auto dma_tile = [&](int wt, int dst) {
     const bf16* xb = X + tile_base(wt);
     unsigned k2_ = pk2;
     asm volatile("" : "+v"(k2_));                                  // (rebuilt per call: see B3_ADDR)
     const unsigned ln = ((k2_ >> 22) & 15u) + 16u * (k2_ >> 26);
+    const unsigned r8 = ln >> 3, c8 = ln & 7u;
+    unsigned voff[2];                                              // byte offset of this lane's 16 bytes inside a piece, pb even / odd
+#pragma unroll
+    for (int o = 0; o < 2; ++o) voff[o] = (r8 * 64u + ((c8 ^ (unsigned)b3_swz((int)(8u * o + r8))) * 8u)) * 2u;
 #pragma unroll
     for (int jj = 0; jj < 5; ++jj) {
       const int j = wave * 5 + jj, t = j >> 3, pb = j & 7;
-      const unsigned row = 8u * pb + (ln >> 3);
-      const unsigned chunk = (ln & 7u) ^ (unsigned)b3_swz((int)row);
-      const bf16* src = xb + (int64_t)t * tstride + (row * 64u + chunk * 8u);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(smem + dst + j * 1024), 16, 0, 0);
+      const bf16* sb = xb + (int64_t)t * tstride + pb * (8 * 64);  // wave-uniform: time step and 8-row block of the piece
+      const unsigned vo = (pb & 1) ? voff[1] : voff[0];
+      const int ldst = dst + j * 1024;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(vo), "s"(sb), "s"(ldst) : "memory");
     }
   };
 
@@ -165,6 +183,11 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __rest
     tab[192 + tid] = -1.44269504088896f * bg[tid];
   }
 
+#ifdef B3_STAMPS
+  unsigned long long* b3_ts = reinterpret_cast<unsigned long long*>(smem + B3_GACC + 2048);   // [8 waves][12]
+  if (tid < 96) b3_ts[tid] = 0ull;
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
   f32x4 accC[3][2], accG[2], accB = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < 3; ++k)
@@ -178,7 +201,9 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __rest
     frag8 dyo[TH_T];
 #pragma unroll
     for (int t = 0; t < TH_T; ++t) dyo[t] = dyn[t];
+    B3_ST(11);
     B3_BARRIER_ALL();                                              // E': x of this tile has landed, everyone left the previous tile
+    B3_ST(0);
     // ---------------- conv(x) + bias of this lane's 8 channels, all time steps ----------------
     f32x4 xh[TH_T][2];
     {
@@ -208,18 +233,18 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __rest
     }
     float rstd;
     {                                                              // exact two-pass statistics of this lane's group (8 ch x 5 t)
-      float s = 0.f;
+      float sp[4] = {0.f, 0.f, 0.f, 0.f};                           // four interleaved partial sums: 10-long dependency chains, not 40
 #pragma unroll
       for (int t = 0; t < TH_T; ++t)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += xh[t][e >> 2][e & 3];
-      const float mean = s * (1.f / 40.f);
-      float qq = 0.f;
+        for (int e = 0; e < 8; ++e) sp[e & 3] += xh[t][e >> 2][e & 3];
+      const float mean = ((sp[0] + sp[1]) + (sp[2] + sp[3])) * (1.f / 40.f);
+      float qp[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < TH_T; ++t)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = xh[t][e >> 2][e & 3] - mean; qq = fmaf(d, d, qq); }
-      rstd = 1.f / sqrtf(qq * (1.f / 40.f) + eps);
+        for (int e = 0; e < 8; ++e) { const float d = xh[t][e >> 2][e & 3] - mean; qp[e & 3] = fmaf(d, d, qp[e & 3]); }
+      rstd = 1.f / sqrtf(((qp[0] + qp[1]) + (qp[2] + qp[3])) * (1.f / 40.f) + eps);
       // ---------------- S1: xhat (kept), n[t] -> N buffer ----------------
       const float nm = -mean * rstd;
       B3_ADDR();
@@ -237,7 +262,9 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __rest
         b3_st(smem, noff + t * B3_TT + oo, th_pack8(n));
       }
     }
+    B3_ST(1);
     B3_BARRIER();                                                  // A: n[t] complete (all channels of every pixel)
+    B3_ST(2);
     // ---------------- S2: gate, dgpre, dres, relu path of dn ----------------
     frag8 dn0[TH_T], dres[TH_T];
     {
@@ -278,10 +305,12 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __rest
         dn0[t] = th_pack8(dnr);
       }
     }
+    B3_ST(3);
     B3_BARRIER();                                                  // B: dgpre[t] complete
+    B3_ST(4);
     // ---------------- S3: gate^T, dn, GroupNorm backward ----------------
     frag8 dcf[TH_T];
-    {
+    auto phase_s3 = [&]() {
       B3_ADDR();
       B3_PARAM(gw, 1);
       frag8 wgT[2][2];
@@ -289,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __rest
       for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
         for (int s = 0; s < 2; ++s) wgT[mm][s] = B3_WT(B3_W + 24 * 1024, mm, s);
-      float S1 = 0.f, S2 = 0.f;
+      float S1p[4] = {0.f, 0.f, 0.f, 0.f}, S2p[4] = {0.f, 0.f, 0.f, 0.f};
       float dgam[8], dbet[8];                                      // this tile's d gamma / d beta of the lane's 8 channels
 #pragma unroll
       for (int e = 0; e < 8; ++e) { dgam[e] = 0.f; dbet[e] = 0.f; }
@@ -311,8 +340,8 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __rest
             dbet[e] += dnv;
             const float d = dnv * gw[e];
             dd[e] = d;
-            S1 += d;
-            S2 = fmaf(d, xv, S2);
+            S1p[r] += d;
+            S2p[r] = fmaf(d, xv, S2p[r]);
           }
         }
         dxh[t] = th_pack8(dd);
@@ -329,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __rest
           __hip_atomic_fetch_add(ga + 8 + e, dbet[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
-      const float m1 = S1 * (1.f / 40.f), m2 = S2 * (1.f / 40.f);
+      const float m1 = ((S1p[0] + S1p[1]) + (S1p[2] + S1p[3])) * (1.f / 40.f), m2 = ((S2p[0] + S2p[1]) + (S2p[2] + S2p[3])) * (1.f / 40.f);
 #pragma unroll
       for (int t = 0; t < TH_T; ++t) {
         float dc[8];
@@ -337,9 +366,9 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __rest
         for (int e = 0; e < 8; ++e) dc[e] = rstd * ((float)dxh[t][e] - m1 - xh[t][e >> 2][e & 3] * m2);
         dcf[t] = th_pack8(dc);
       }
-    }
+    };
     // ---------------- P2: gate weight gradient (rows 16q.., columns 32h..) ----------------
-    {
+    auto phase_p2 = [&]() {
       B3_ADDR();
       B3_ONES(1);
 #pragma unroll
@@ -352,8 +381,17 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __rest
           accB = mfma16(af, ones, accB);
         }
       }
-    }
+    };
+    // Both need only what barrier B published.  P2 first: its transposing reads and MFMAs are issued while dn0 / xh are merely parked,
+    // and the allocation closes without a spill in this order.  (Letting the two waves of a SIMD take the phases in opposite order --
+    // one in the vector-ALU chain while its partner streams LDS reads into MFMAs -- costs 50 spilled registers at the join of the two
+    // code paths, as a branch and as a two-trip loop alike.)
+    phase_p2();
+    B3_ST(5);
+    phase_s3();
+    B3_ST(6);
     B3_BARRIER();                                                  // C: everyone is done with n[t], dgpre[t]
+    B3_ST(7);
     // ---------------- the next tile's x -> N buffer (LDS-DMA), its dy -> registers; publish dconv[t] ----------------
     const int wtn = wt + gridDim.x;
     if (wtn < ntile) dma_tile(wtn, noff);
@@ -368,7 +406,9 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __rest
 #pragma unroll
       for (int t = 0; t < TH_T; ++t) b3_st(smem, aoff + t * B3_TT + oo, dcf[t]);
     }
+    B3_ST(8);
     B3_BARRIER();                                                  // D (LDS only: the DMA and the dy loads stay in flight)
+    B3_ST(9);
     // ---------------- dx[t'] = sum_k W_k^T dconv[t' - (k-1) d] + dres[t'] (this wave's 8 channels per lane) ----------------
     {
       B3_ADDR();
@@ -401,6 +441,7 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __rest
         *reinterpret_cast<frag8*>(dxb + t * tstride + le_) = th_pack8(y);
       }
     }
+    B3_ST(10);
     // ---------------- P4: conv weight gradients  dW_k += dconv[tp - (k-1) d]^T x[tp] ----------------
     {
       B3_ADDR();
@@ -426,6 +467,9 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __rest
     const int tmp = xoff; xoff = noff; noff = tmp;                 // the DMA target becomes X, the old X buffer receives the next n[t]
   }
   B3_BARRIER_ALL();
+#ifdef B3_STAMPS
+  if (tid < 96) b3_dbg[(size_t)blockIdx.x * 96 + tid] = b3_ts[tid];
+#endif
   // ---------------- write this workgroup's slab (rows 16q.., columns 32h..) ----------------
   B3_ADDR();
   float* my = slab + (int64_t)blockIdx.x * TH_SLAB;

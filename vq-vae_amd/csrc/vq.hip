@@ -742,10 +742,12 @@ struct CodeEpi {
 };
 
 // EMA update (scripts/train_vqvae.py:412-414): N_k, m_k moving averages + Laplace-smoothed codebook
+// ok (optional device float): <= 0 leaves the running averages and the codebook untouched (isfinite guard of the train step)
 __global__ __launch_bounds__(256) void vq_ema_kernel(const float* __restrict__ sums, const int32_t* __restrict__ counts, int K, int d,
                                                      float decay, float eps, float* __restrict__ ema_count,
-                                                     float* __restrict__ ema_sum, float* __restrict__ E) {
+                                                     float* __restrict__ ema_sum, float* __restrict__ E, const float* __restrict__ ok) {
   __shared__ double red[256];
+  if (ok != nullptr && !(ok[0] > 0.f)) return;
   double s = 0.0;
   for (int k = threadIdx.x; k < K; k += 256) {
     const float nc = decay * ema_count[k] + (1.f - decay) * (float)counts[k];
@@ -962,8 +964,8 @@ int frl_vq_bwd(const void* g_out, const void* z, const void* zq, const float* E,
 // EMA codebook update from this batch's assignments: counts [K] int32 and per-code sums [K][d] f32
 // (both produced by frl_vq_assign_fwd / frl_vq_bwd(sums_out)).  Updates ema_count, ema_sum, E in place.
 int frl_vq_ema_update(const float* sums, const int32_t* counts, int K, int d, float decay, float eps, float* ema_count,
-                      float* ema_sum, float* E, hipStream_t stream) {
-  FRL_LAUNCH(vq_ema_kernel, dim3(1), dim3(256), 0, stream, sums, counts, K, d, decay, eps, ema_count, ema_sum, E);
+                      float* ema_sum, float* E, const float* ok, hipStream_t stream) {
+  FRL_LAUNCH(vq_ema_kernel, dim3(1), dim3(256), 0, stream, sums, counts, K, d, decay, eps, ema_count, ema_sum, E, ok);
   return frl_check_launch("vq_ema_update");
 }
 

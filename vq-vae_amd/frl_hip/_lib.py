@@ -28,6 +28,8 @@ SIGNATURES = {
     "frl_version": (c_int, []),
     "frl_last_error": (c_char_p, []),
     "frl_device_arch": (c_int, [c_char_p, I]),
+    "frl_kernel_timing_enable": (c_int, [I]),
+    "frl_kernel_timing_report": (c_int, [c_char_p, I]),
     "frl_conv_workspace_bytes": (S, [I, I, I]),
     "frl_conv1x1_fwd": (c_int, [P, P, P, P, L, I, I, I, I, P, S, P]),
     "frl_conv1x1_bwd_data": (c_int, [P, P, I, P, P, L, I, I, I, P, S, P]),
@@ -37,7 +39,7 @@ SIGNATURES = {
     "frl_vq_workspace_bytes": (S, [L, I, I]),
     "frl_vq_assign_fwd": (c_int, [P, P, L, I, I, P, P, P, P, I, P, S, P]),
     "frl_vq_bwd": (c_int, [P, P, P, P, P, P, P, F, L, I, I, P, P, P, I, P, S, P]),
-    "frl_vq_ema_update": (c_int, [P, P, I, I, F, F, P, P, P, P]),
+    "frl_vq_ema_update": (c_int, [P, P, I, I, F, F, P, P, P, P, P]),
     "frl_vq_revive_dead_codes": (c_int, [P, P, L, P, L, I, I, ctypes.c_uint64, P, P, P, I, P]),
     "frl_groupnorm_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, F, I, I, P]),
     "frl_groupnorm_bwd_workspace_bytes": (S, [I, I, I]),
@@ -82,7 +84,7 @@ SIGNATURES = {
     "frl_tcn_hot_bwd_workspace_bytes": (S, [L]),
     "frl_tcn_hot_fwd": (c_int, [P, P, P, P, P, P, P, P, P, L, I, I, F, P, S, P]),
     "frl_tcn_hot_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, F, P, S, P]),
-    "frl_tcn_hot_force_generic_tiles": (None, [I]),
+    "frl_tcn_hot_force_generic_tiles": (c_int, [I]),
     "frl_tcn_block_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, F, I, P, S, P]),
 }
 

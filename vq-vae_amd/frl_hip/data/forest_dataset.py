@@ -17,12 +17,42 @@ import torch
 from torch.utils.data import Dataset
 
 
-class ForestDataset(Dataset):
+class LegacySchemaMixin:
+    """Attributes the legacy VQ-VAE trainer reads off its dataset (scripts/train_vqvae.py:153-180,217): `cont_names` (the continuous
+    features -> `cont_dim`), `cat_names` / `schema_cat` (categorical inputs and their vocabularies), `naip` (image patch array whose
+    last axis is the band count) and `class_weights_by_cat_name(name)`.  A (time, y, x, feature) tile store holds continuous features
+    only: no categorical inputs, no NAIP bands -- so the script's own loops build an empty `cat_vocab_sizes` and `naip_bands = 0`,
+    which is what `VQVAE(cont_dim=..., cat_vocab_sizes={}, naip_bands=0, ...)` accepts.  Needs `self.channel_names`."""
+
+    @property
+    def cont_names(self) -> List[str]:
+        return list(self.channel_names)
+
+    @property
+    def cat_names(self) -> List[str]:
+        return []
+
+    @property
+    def schema_cat(self) -> Dict[str, dict]:
+        return {}
+
+    @property
+    def naip(self) -> np.ndarray:
+        return np.zeros((0, 0, 0), dtype=np.float32)                # (krow, kcol, band): no bands
+
+    def class_weights_by_cat_name(self, name: str):
+        raise KeyError(f"no categorical input {name!r}: the tile dataset has none (cat_names is empty)")
+
+
+class ForestDataset(LegacySchemaMixin, Dataset):
     def __init__(self, num_tiles: int = 1024, time: int = 5, size: int = 32, features: int = 64, seed: int = 1234,
-                 channels_first: bool = False, partial_edge: Optional[int] = None):
+                 channels_first: bool = False, partial_edge: Optional[int] = None, tiles_per_chunk: int = 64):
         self.num_tiles, self.time, self.size, self.features = num_tiles, time, size, features
         self.seed, self.channels_first, self.partial_edge = seed, channels_first, partial_edge
         self.channel_names = [f"f{i:03d}" for i in range(features)]
+        # chunk membership for the chunk-locked batch sampler (train_vqvae.py:153-159): consecutive tiles share a synthetic chunk
+        self.xy_by_chunk = [np.arange(lo, min(lo + tiles_per_chunk, num_tiles), dtype=np.int64)
+                            for lo in range(0, num_tiles, max(int(tiles_per_chunk), 1))]
 
     def __len__(self) -> int:
         return self.num_tiles

@@ -22,11 +22,12 @@ import torch
 from torch.utils.data import Dataset
 
 from .. import _lib
+from .forest_dataset import LegacySchemaMixin
 from .normalization import norm_table, presets_from_meta
 from .tile_store import TileStore
 
 
-class ChunkTileDataset(Dataset):
+class ChunkTileDataset(LegacySchemaMixin, Dataset):
     def __init__(self, store: TileStore, tile: int = 32):
         t, cy, cx, f = store.chunks
         if cy % tile or cx % tile:

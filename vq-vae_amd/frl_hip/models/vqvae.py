@@ -14,6 +14,7 @@ from __future__ import annotations
 from typing import Dict, Optional
 
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 
 from .. import functional as Fh
@@ -43,6 +44,10 @@ class VectorQuantizer(nn.Module):
             self.register_buffer("ema_count", torch.zeros(codebook_size))
             self.register_buffer("ema_sum", self.codebook.detach().clone())
         self.last_counts: Optional[torch.Tensor] = None
+        # A trainer that guards the step against a non-finite loss sets defer_ema: the statistics of the batch are then kept until
+        # apply_ema(ok) -- after the loss is known -- instead of being folded into the running averages inside forward().
+        self.defer_ema = False
+        self._pending_ema = None
 
     def forward(self, z_rows: torch.Tensor):
         """z_rows [N, d] -> (z_q [N,d] with straight-through gradient, vq_loss, perplexity, idx int32 [N])."""
@@ -54,19 +59,58 @@ class VectorQuantizer(nn.Module):
                 with torch.no_grad():
                     _, _, sums = ops.vq_bwd(None, z_rows.detach(), self.codebook.detach(), idx, counts, None, 0.0,
                                             want_gz=False, want_ge=False, want_sums=True)
-                    ops.vq_ema_update(sums, counts, self.ema_count, self.ema_sum, self.codebook.data, self.ema_decay, self.ema_eps)
+                self._pending_ema = (sums, counts)
+                if not self.defer_ema:
+                    self.apply_ema()
         else:
             vq_loss = l_cb + self.beta * l_cm
         return zq, vq_loss, perp, idx
+
+    @torch.no_grad()
+    def apply_ema(self, ok: Optional[torch.Tensor] = None) -> None:
+        """Folds the batch statistics kept by forward() into the running averages and rewrites the codebook.  Data parallel: the
+        per-code counts and sums are summed over the ranks first (the codebook is no parameter here, so it is in no gradient bucket:
+        without this every rank would drift to its own codebook).  `ok` (device float [1], <= 0 = non-finite loss) gates the update
+        on the device; pass ok=False-like host values by simply not calling this and using drop_ema()."""
+        if self._pending_ema is None:
+            return
+        sums, counts = self._pending_ema
+        self._pending_ema = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            counts = counts.clone()                                        # last_counts keeps this rank's own batch
+            dist.all_reduce(sums)
+            dist.all_reduce(counts)
+        ops.vq_ema_update(sums, counts, self.ema_count, self.ema_sum, self.codebook.data, self.ema_decay, self.ema_eps, ok)
+        torch.autograd.graph.increment_version(self.codebook)
+
+    def drop_ema(self) -> None:
+        self._pending_ema = None
 
 
 class VQVAE(RepresentationModel):
     """Encoder -> VQ(z_type) -> type decoder ; phase path conditioned on stopgrad(z_type_cont) -> phase decoder."""
 
-    def __init__(self, in_features: int = 64, codebook_size: int = 256, emb_dim: int = 64, beta: float = 0.25,
+    def __init__(self, in_features: Optional[int] = None, codebook_size: int = 256, emb_dim: int = 64, beta: float = 0.25,
                  hidden: int = 128, quantizer: str = "st", ema_decay: float = 0.99, ema_eps: float = 1e-5,
                  phase: bool = True, phase_codebook_size: int = 0, lambda_recon: float = 1.0, lambda_vq: float = 1.0,
+                 cont_dim: Optional[int] = None, cat_vocab_sizes=None, naip_bands: Optional[int] = None, cat_emb_dim: int = 8,
                  **repr_kwargs):
+        # Legacy constructor call (scripts/train_vqvae.py:183-195): VQVAE(cont_dim=, cat_vocab_sizes=, naip_bands=, emb_dim=,
+        # codebook_size=, beta=, hidden=, quantizer=, cat_emb_dim=, ema_decay=, ema_eps=).  `cont_dim` is the number of continuous
+        # features = the tile's feature axis (alias of in_features).  The tile VQ-VAE has no categorical embeddings and no NAIP
+        # image branch (the `vqvae` package that defined them is absent from the reference tree, SURVEY.md fact 2): an empty
+        # vocabulary table and any band count are accepted and recorded, a non-empty table is refused instead of being ignored.
+        if cont_dim is not None:
+            if in_features is not None and int(in_features) != int(cont_dim):
+                raise ValueError(f"cont_dim ({cont_dim}) and in_features ({in_features}) name the same axis and disagree")
+            in_features = int(cont_dim)
+        if in_features is None:
+            in_features = 64
+        if cat_vocab_sizes:
+            raise ValueError("cat_vocab_sizes is not empty: categorical inputs are not part of the (time, y, x, feature) tile VQ-VAE "
+                             f"(got {sorted(dict(cat_vocab_sizes))}); pass an empty mapping")
+        self_legacy = dict(cat_vocab_sizes=dict(cat_vocab_sizes or {}), naip_bands=None if naip_bands is None else int(naip_bands),
+                           cat_emb_dim=int(cat_emb_dim))
         repr_kwargs.setdefault("z_type_dim", emb_dim)
         if repr_kwargs["z_type_dim"] != emb_dim:
             raise ValueError("emb_dim must equal z_type_dim (the quantizer acts on z_type)")
@@ -74,6 +118,7 @@ class VQVAE(RepresentationModel):
             repr_kwargs["type_encoder_channels"] = (128, emb_dim)
         super().__init__(type_in_channels=in_features, phase_in_channels=in_features, **repr_kwargs)
         self.in_features, self.phase, self.lambda_recon, self.lambda_vq = in_features, phase, lambda_recon, lambda_vq
+        self.cont_dim, self.legacy_inputs = in_features, self_legacy
         self.quant = VectorQuantizer(codebook_size, emb_dim, beta, quantizer, ema_decay, ema_eps)
         self.decoder_type = Conv2DHead(emb_dim, [hidden], in_features)
         if phase:
@@ -82,6 +127,8 @@ class VQVAE(RepresentationModel):
                 self.quant_phase = VectorQuantizer(phase_codebook_size, self.z_phase_dim, beta, quantizer, ema_decay, ema_eps)
         self.codebook_manager = None
         self._manager_takes_rows = False
+        self.defer_codebook_hooks = False                   # set by a trainer with an isfinite guard: see commit_codebook_hooks
+        self._pending_manager = None
         self.fused_decoder = True
         # The phase path is conditioned on stopgrad(z_type): forward AND backward of the two branches are independent, so the phase
         # branch runs on a side HIP stream next to VQ + type decoder (forward) and next to the whole type-path backward.
@@ -179,11 +226,41 @@ class VQVAE(RepresentationModel):
             out.update(ph)
         out["loss"] = loss
         if self.codebook_manager is not None and hasattr(self.codebook_manager, "update") and self.training:
-            if self._manager_takes_rows:
-                self.codebook_manager.update(self.quant.last_counts, z_type.detach().reshape(-1, d))
-            else:                                                           # a manager with the bare update(counts) signature
-                self.codebook_manager.update(self.quant.last_counts)
+            self._pending_manager = (self.quant.last_counts, z_type.detach().reshape(-1, d))
+            if not self.defer_codebook_hooks:
+                self.commit_codebook_hooks()
         return out
+
+    def _quantizers(self):
+        return [q for q in (getattr(self, "quant", None), getattr(self, "quant_phase", None)) if q is not None]
+
+    def set_defer_codebook_hooks(self, on: bool) -> None:
+        """on: forward_tiles no longer mutates codebook state (EMA running averages, the manager's usage window); the caller commits it
+        with commit_codebook_hooks(ok) once it knows whether the batch counts (the reference skips a batch with a non-finite loss,
+        frl/training/representation/step.py:1057-1074) or discards it with drop_codebook_hooks()."""
+        self.defer_codebook_hooks = bool(on)
+        for qz in self._quantizers():
+            qz.defer_ema = bool(on)
+
+    def commit_codebook_hooks(self, ok: Optional[torch.Tensor] = None) -> None:
+        for qz in self._quantizers():
+            if qz.quantizer == "ema":
+                qz.apply_ema(ok)
+        pend, self._pending_manager = self._pending_manager, None
+        if pend is not None and self.codebook_manager is not None:
+            counts, rows = pend
+            if self._manager_takes_rows:
+                if ok is not None:
+                    self.codebook_manager.update(counts, rows, ok=ok)
+                else:
+                    self.codebook_manager.update(counts, rows)
+            else:                                                           # a manager with the bare update(counts) signature
+                self.codebook_manager.update(counts if ok is None else counts * (ok > 0).to(counts.dtype))
+
+    def drop_codebook_hooks(self) -> None:
+        self._pending_manager = None
+        for qz in self._quantizers():
+            qz.drop_ema()
 
     def forward(self, batch, return_gate: bool = False):
         """Legacy contract (scripts/train_vqvae.py:287): dict batch -> (cont_pred, cat_logits, canopy_pred, vq_loss, perplexity).

@@ -32,6 +32,22 @@ def timing_summary():
     return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in _TIMING["events"].items()}
 
 
+def kernel_timing(on: bool) -> None:
+    """Library-side HIP-event pair around every kernel launch (see include/frl_hip.h: frl_kernel_timing_enable)."""
+    _lib.load().frl_kernel_timing_enable(1 if on else 0)
+
+
+def kernel_timing_report():
+    """kernel expression -> (calls, total_ms) since the last report; synchronises the recorded events."""
+    buf = ctypes.create_string_buffer(1 << 16)
+    _lib.load().frl_kernel_timing_report(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, calls, ms = line.rsplit("\t", 2)
+        out[name] = (int(calls), float(ms))
+    return out
+
+
 class span:
     """with ops.span("name"): ...  -- HIP-event timing of a sub-range (used for single-kernel roofline numbers)."""
 
@@ -197,10 +213,13 @@ def vq_bwd(g_out: Optional[torch.Tensor], z: torch.Tensor, codebook: torch.Tenso
     return gz, ge, sums
 
 
-def vq_ema_update(sums, counts, ema_count, ema_sum, codebook, decay: float, eps: float):
+def vq_ema_update(sums, counts, ema_count, ema_sum, codebook, decay: float, eps: float, ok: Optional[torch.Tensor] = None):
+    """EMA codebook update in place; `ok` (device float [1]) <= 0 skips it on the device (isfinite guard, no host sync)."""
     k, d = codebook.shape
+    if ok is not None and (ok.dtype != torch.float32 or not ok.is_cuda or ok.numel() < 1):
+        raise ValueError("vq_ema_update: ok must be a float32 CUDA tensor")
     check(_lib.load().frl_vq_ema_update(_p(sums), _p(counts), k, d, float(decay), float(eps), _p(ema_count),
-                                        _p(ema_sum), _p(codebook), _stream()), "frl_vq_ema_update")
+                                        _p(ema_sum), _p(codebook), _p(ok), _stream()), "frl_vq_ema_update")
 
 
 # ----------------------------------------------------------------------------------------------

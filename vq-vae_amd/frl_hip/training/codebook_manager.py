@@ -32,9 +32,12 @@ class CodebookManager:
         self.revived: Optional[torch.Tensor] = None         # int32 [1] running total (device)
         self.steps = 0
         self._z: Optional[torch.Tensor] = None
+        self._z_ok: Optional[torch.Tensor] = None            # device flag of the batch whose rows are kept (None: unguarded)
 
-    def update(self, counts: Optional[torch.Tensor], z_rows: Optional[torch.Tensor] = None) -> None:
-        """counts: int32 [K] assignments of this batch; z_rows: the encoder outputs [N, d] that were quantized (kept for revival)."""
+    def update(self, counts: Optional[torch.Tensor], z_rows: Optional[torch.Tensor] = None, ok: Optional[torch.Tensor] = None) -> None:
+        """counts: int32 [K] assignments of this batch; z_rows: the encoder outputs [N, d] that were quantized (kept for revival);
+        ok: optional device float [1] of the train step's isfinite guard -- a batch with ok <= 0 adds nothing to the window and its
+        rows never seed a code (all on the device, no host synchronisation)."""
         if counts is None:
             return
         if counts.numel() != self.num_codes:
@@ -42,9 +45,11 @@ class CodebookManager:
         if self.window is None:
             self.window = torch.zeros(self.num_codes, dtype=torch.int64, device=counts.device)
             self.revived = torch.zeros(1, dtype=torch.int32, device=counts.device)
+        if ok is not None:
+            counts = counts.to(torch.int64) * (ok.reshape(-1)[:1] > 0).to(torch.int64)
         self.window += counts
         if z_rows is not None:
-            self._z = z_rows.detach()
+            self._z, self._z_ok = z_rows.detach(), ok
 
     def usage(self) -> torch.Tensor:
         """Fraction of the window's assignments per code (device tensor)."""
@@ -71,14 +76,17 @@ class CodebookManager:
             st = optimizer.state[cb]
             m, v = st.get("exp_avg"), st.get("exp_avg_sq")
         z = self._z if self._z.is_contiguous() else self._z.contiguous()
-        ops.vq_revive_dead_codes(cb.data, self.window, self.min_count, z, self.seed + self.steps, m, v, self.revived)
+        window = self.window
+        if self._z_ok is not None:                           # candidate rows of a skipped (non-finite) batch: revive nothing this time
+            window = torch.where(self._z_ok.reshape(-1)[:1] > 0, window, torch.full_like(window, self.min_count))
+        ops.vq_revive_dead_codes(cb.data, window, self.min_count, z, self.seed + self.steps, m, v, self.revived)
         torch.autograd.graph.increment_version(cb)
         if distributed:
             dist.broadcast(cb.data, src=0)
         if hasattr(quantizer, "ema_sum"):                                     # EMA quantizer: keep its running sums consistent
-            dead = self.window < self.min_count
+            dead = window < self.min_count
             quantizer.ema_sum[dead] = cb.data[dead]
             quantizer.ema_count[dead] = 1.0
         self.window.zero_()
-        self._z = None
+        self._z = self._z_ok = None
         return True
