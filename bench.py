@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; nccl == RCCL (the measured configuration), gloo only to rehearse the N>1 control flow")
     ap.add_argument("--torch-optimizer", action="store_true", help="A/B: clip_grad_norm_ + torch.optim.AdamW instead of the two HIP launches")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the train step from a captured hipGraph (VQVAETrainer.step_graphed); auto: whenever the trainer supports it")
     ap.add_argument("--phase-codebook", type=int, default=0, help="second codebook on z_phase (BASELINE configs[4])")
     ap.add_argument("--extra", action="store_true",
                     help="N=1 only: also time BASELINE configs[3] (K=8192, d=128), configs[4] at one GPU (T=10, 64x64, two codebooks of 1024) "
@@ -136,15 +138,19 @@ def build_trainer(args, dev, dtype, codebook, emb_dim, phase_codebook=0, serial=
     return model, trainer
 
 
-def timed_steps(trainer, stream, steps, warmup, barrier):
+def timed_steps(trainer, stream, steps, warmup, barrier, graphed=False):
     """W untimed + exactly K timed steps bracketed by barrier + synchronize; returns (seconds, host seconds to queue the K steps, last out)."""
+    step = trainer.step_graphed if graphed else trainer.step
+    if graphed:                                       # set-up, before the W warm-up steps: one capture per buffer of the tile pool
+        for _ in range(len(stream.tiles)):
+            step(stream.next())
     for _ in range(warmup):
-        trainer.step(stream.next())
+        step(stream.next())
     barrier()
     t0 = time.perf_counter()
     last = None
     for _ in range(steps):                            # timed region: exactly K steps, no instrumentation
-        last = trainer.step(stream.next())
+        last = step(stream.next())
     t_host = time.perf_counter() - t0                 # the host has queued everything; the device may still be running
     barrier()
     return time.perf_counter() - t0, t_host, last
@@ -162,7 +168,7 @@ def extra_lines(args, dev, barrier):
     for name, c in cases:
         model, trainer = build_trainer(args, dev, c["dtype"], c["K"], c["d"], c["pK"])
         stream = SyntheticTileStream(c["B"], c["T"], c["S"], args.features, device=dev, dtype=c["dtype"], seed=1234)
-        dt, th, last = timed_steps(trainer, stream, 10, 3, barrier)
+        dt, th, last = timed_steps(trainer, stream, 10, 3, barrier, graphed=args.graph != "off" and trainer.graph_supported())
         out[name] = {"tiles/s": round(c["B"] * 10 / dt, 1), "ms_per_step": round(1e2 * dt, 3), "host_ms_per_step": round(1e2 * th, 3),
                      "steps": 10, "warmup": 3, "loss": round(float(last["loss"].detach()), 5)}
         del model, trainer, stream, last
@@ -206,18 +212,24 @@ def main():
         torch.cuda.synchronize()
 
     timing = (not args.no_kernel_timing) and rank == 0
-    dt, t_host, last = timed_steps(trainer, stream, args.steps, args.warmup, barrier)
-    ksum, ksteps = {}, 0
+    graphed = args.graph != "off" and trainer.graph_supported()
+    if args.graph == "on" and not graphed:
+        raise SystemExit("bench.py: --graph on, but this trainer configuration cannot be captured (data-parallel reducer or a per-step lambda_vq)")
+    dt, t_host, last = timed_steps(trainer, stream, args.steps, args.warmup, barrier, graphed)
+    ksum, kern, ksteps = {}, {}, 0
     if not args.no_kernel_timing:                     # separate instrumented steps: HIP events around every C-ABI call (rank 0)
         ksteps = max(2, min(5, args.steps))           # EVERY rank runs them: a step contains collectives
         model.concurrent_phase = False                # per-kernel spans are only meaningful without the two branches overlapping
         if timing:
-            ops.set_timing(True)
+            ops.set_timing(True)                      # HIP events around every C-ABI call (op families) ...
+            ops.kernel_timing(True)                   # ... and, inside the library, around every single kernel launch
         for _ in range(ksteps):
             trainer.step(stream.next())
         if timing:
             ksum = ops.timing_summary()
+            kern = ops.kernel_timing_report()
             ops.set_timing(False)
+            ops.kernel_timing(False)
     if world > 1:
         barrier()
     rank_ms = [1e3 * dt / args.steps]
@@ -245,6 +257,7 @@ def main():
                                f"fwd+bwd+clip+AdamW), {args.batch} tiles/GPU of {args.time}x{args.size}x{args.size}x{args.features}, "
                                f"K={args.codebook}, d={args.emb_dim}, dropout 0.0",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}", "finite_check": not args.no_finite_check,
+                   "launch": "hipGraph replay of the whole step (one graph per tile-pool buffer)" if graphed else "eager (one launch per kernel)",
                    "loss": round(float(last["loss"].detach()), 5), "perplexity": round(float(last["perplexity"]), 2)},
         "host_ms_per_step": round(1e3 * t_host / args.steps, 3),
         "rank_ms_per_step": {"max": round(max(rank_ms), 3), "min": round(min(rank_ms), 3)},
@@ -255,14 +268,24 @@ def main():
         n = args.batch * args.size * args.size                      # vectors / pixels per step
         s = 2 if args.dtype == "bf16" else 4
         out["kernels"] = {k: {"calls_per_step": c / args.steps, "ms_per_step": round(ms / args.steps, 4)} for k, (c, ms) in ksum.items()}
+        # every kernel the library launched, event pair recorded inside the library right around the launch (the live counterpart of
+        # the rocprofv3 kernel trace under profiles/)
+        out["gpu_kernels"] = {k: {"launches_per_step": c / args.steps, "avg_us": round(1e3 * ms / c, 2), "ms_per_step": round(ms / args.steps, 4)}
+                              for k, (c, ms) in sorted(kern.items(), key=lambda kv: -kv[1][1])}
+        out["gpu_kernel_ms_per_step"] = round(sum(ms for _, ms in kern.values()) / args.steps, 3)
         # --- VQ assign: HBM roofline, algorithmic bytes = 2*d*s + 4 per vector (+ K*d*4 codebook once)
         vq_ms = ksum["vq_assign"][1] / ksum["vq_assign"][0]
         vq_bytes = n * (2 * args.emb_dim * s + 4) + args.codebook * args.emb_dim * 4
         out["vq_hbm"] = {"GB/s": round(vq_bytes / vq_ms / 1e6, 1), "frac": round(vq_bytes / vq_ms / 1e6 / HBM_PEAK_GBS, 4),
                          "ms": round(vq_ms, 4), "bytes": vq_bytes,
                          "note": "live HIP-event span of the whole frl_vq_assign_fwd call (every kernel the call launches)"}
+        kv = [v for k, v in kern.items() if "vq_assign" in k]
+        if kv:                                                # the L2/argmin kernel alone (library-side event pair around its launch)
+            us = 1e3 * sum(ms for _, ms in kv) / sum(c for c, _ in kv)
+            out["vq_hbm"]["assign_kernel"] = {"us": round(us, 2), "GB/s": round(vq_bytes / us / 1e3, 1),
+                                              "frac": round(vq_bytes / us / 1e3 / HBM_PEAK_GBS, 4)}
         ku = profiled_kernel_us("vq_assign_kernel")
-        if ku is not None:                                    # the L2/argmin kernel alone, from the committed rocprofv3 kernel trace
+        if ku is not None:                                    # ... and from the committed rocprofv3 kernel trace
             out["vq_hbm"]["assign_kernel_rocprof"] = {"us": ku[0], "GB/s": round(vq_bytes / ku[0] / 1e3, 1),
                                                       "frac": round(vq_bytes / ku[0] / 1e3 / HBM_PEAK_GBS, 4), "source": ku[1]}
         # --- conv MFMA: algorithmic dense FLOPs of the step (3 x forward) over the event time of every conv / TCN op
@@ -277,10 +300,18 @@ def main():
             out["conv_mfma"]["mfma_util"] = mu
         # --- dominant kernel -> headline roofline object
         # dominant kernel FAMILY among those with a per-launch work model below (the fused TCN kernels at the measured configuration)
-        modelled = ("tcn_block_bwd.main", "tcn_block_fwd", "vq_assign", "edge_smooth_fwd", "edge_smooth_bwd")
-        cands = [k for k in ksum if k in modelled]
-        dom = max(cands, key=lambda k: ksum[k][1])
-        out["roofline"] = roofline_for(dom, ksum, args, model, n, s)
+        # (kernel families with a per-launch work model; time = the library-side event pairs around the kernel launches themselves)
+        fam = {"tcn_block_bwd.main": "tcn_hot_bwd", "tcn_block_fwd": "tcn_hot_fwd", "vq_assign": "vq_assign_kernel",
+               "edge_smooth_fwd": "smooth_fwd", "edge_smooth_bwd": "smooth_bwd"}
+        ftime = {}
+        for name, sub in fam.items():
+            hit = [v for k, v in kern.items() if sub in k]
+            if hit:
+                ftime[name] = (sum(c for c, _ in hit), sum(ms for _, ms in hit))
+        if not ftime:                                               # (generic kernels only, e.g. --dtype f32): fall back to the op spans
+            ftime = {k: ksum[k] for k in fam if k in ksum}
+        dom = max(ftime, key=lambda k: ftime[k][1])
+        out["roofline"] = roofline_for(dom, ftime, args, model, n, s)
         args.steps = args.steps_timed
     if world == 1 and args.extra:
         del trainer, stream, last
@@ -360,8 +391,9 @@ def roofline_for(name, ksum, args, model, n, s):
         first, second = (hbm, mfma) if hf >= mf else (mfma, hbm)
         base.update(first)
         base["other_ceiling"] = second
-        base["note"] = ("latency / synchronisation bound today (SQ counters: 64% of wave time parked at s_waitcnt or barriers), vector-ALU "
-                        "floor ~140 us per launch (about 36 VALU ops per element of the GroupNorm/gate chain); see DESIGN.md section 4")
+        base["note"] = ("HIP-event pair inside the library around the kernel launch itself (weight pack and slab reduction of the C-ABI call "
+                        "excluded); per tile the vector ALU, the matrix cores and the LDS each need ~7.5k cycles and the phases run them "
+                        "one after the other (~30k cycles): DESIGN.md section 4")
         return base
     if name == "vq_assign":
         b = n * (2 * d * s + 4) + args.codebook * d * 4

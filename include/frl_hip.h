@@ -151,11 +151,13 @@ int frl_tcn_hot_force_generic_tiles(int on);   /* returns the previous setting *
  * corrections in float64 as torch.optim.AdamW); max_norm <= 0 disables clipping; norm_out (device float, may be NULL) receives
  * the pre-clip global gradient norm.  ok (device float, may be NULL): the reference's isfinite guard evaluated ON THE DEVICE --
  * ok[0] <= 0 leaves parameters and moments untouched; counters (device int[2], may be NULL) = {updates applied, updates skipped},
- * and when given, counters[0] + 1 replaces `step` as the update number (exact under skipped batches, no host sync). */
+ * and when given, counters[0] + 1 replaces `step` as the update number (exact under skipped batches, no host sync).
+ * lr_dev (device float, may be NULL): when given, lr_dev[0] replaces `lr` -- the learning rate of a train step captured in a
+ * hipGraph is written to that word before every replay (per-batch scheduler.step() of loops.py:110 without re-capturing). */
 size_t frl_adamw_workspace_bytes(void);
 int frl_adamw_clip_step(const void* desc_host, int ntensors, const void* chunks, const int* chunk_tensor, int nchunks, float max_norm,
                         float lr, double beta1, double beta2, float eps, int step, float* norm_out, const float* ok, int* counters,
-                        void* ws, size_t ws_bytes, frl_stream_t stream);
+                        const float* lr_dev, void* ws, size_t ws_bytes, frl_stream_t stream);
 /* dst[i] = scale * src[i] over a HOST table of {const float* src; float* dst; int64_t n} records (24 bytes; src NULL -> zeros):
  * flattens the scattered gradients of a bucket for the data-parallel all-reduce in one launch. */
 int frl_multi_tensor_scale_copy(const void* desc_host, int ntensors, const void* chunks, const int* chunk_tensor, int nchunks, float scale,
@@ -222,6 +224,16 @@ int frl_decoder_mse_bwd(const void* z, const float* w1, const float* b1, const f
 size_t frl_vq_workspace_bytes(int64_t N, int K, int d);
 int frl_vq_assign_fwd(const void* z, const float* E, int64_t N, int K, int d, int32_t* idx_out, void* zq_out,
                       float* stats_out, int32_t* counts_out, int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
+/* Prepared codebook (||e||^2 + the packed MFMA fragment image of -2 e): it depends on the codebook content and dtype only, so a
+ * caller that knows when the codebook changes (once per optimizer step; never during inference) builds it once and the assignment
+ * itself is ONE kernel launch behind a memset node: arg-min on the matrix cores, exact float64 re-evaluation of near-ties while the
+ * codebook is still in LDS, z_q gather, squared error, code histogram (integer atomics) and the statistics (folded by the workgroup
+ * that arrives last) -- when the codebook fits one LDS chunk (K * d_pad * sizeof(dtype) <= 64 KB), else as frl_vq_assign_fwd. */
+size_t frl_vq_prepared_bytes(int K, int d);
+int frl_vq_prepare(const float* E, int64_t N, int K, int d, int dtype, void* prep, size_t prep_bytes, frl_stream_t stream);
+int frl_vq_assign_fwd_prepared(const void* z, const float* E, const void* prep /* NULL: prepare inside the call */, int64_t N, int K, int d,
+                               int32_t* idx_out, void* zq_out, float* stats_out, int32_t* counts_out, int dtype, void* ws,
+                               size_t ws_bytes, frl_stream_t stream);
 int frl_vq_bwd(const void* g_out, const void* z, const void* zq /* optional */, const float* E, const int32_t* idx, const int32_t* counts,
                const float* gscale, float beta, int64_t N, int K, int d, void* g_z_out, float* g_E_out, float* sums_out,
                int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
@@ -234,6 +246,25 @@ int frl_vq_ema_update(const float* sums, const int32_t* counts, int K, int d, fl
  * encoder row z[splitmix64(seed + k) mod N], their AdamW moment rows m / v (optional) are cleared, *revived += number of codes. */
 int frl_vq_revive_dead_codes(float* E, const int64_t* window_counts, int64_t min_count, const void* z, int64_t N, int K, int d,
                              uint64_t seed, float* m, float* v, int32_t* revived, int dtype, frl_stream_t stream);
+
+/* ---- sparse-location gather + InfoNCE over mined pairs (csrc/contrastive.hip) -----------------------------
+ * frl_gather_locations_fwd: extract_at_locations of frl/utils/spatial.py:132-173 -- out[n][c] = feat[c*sC + row_n*sH + col_n*sW] for
+ * coords [N][2] int64 (row, col; negative counts from the end), any element strides (NHWC rows and the reference's [C,H,W] view alike).
+ * frl_segment_sum_rows: out[key][:] (+)= sum over each run of equal keys_sorted of vals[order[i]][:], rows added in list order -- the
+ * bit-reproducible scatter-add behind both backward passes (order NULL = identity).
+ * frl_infonce_fwd / frl_infonce_pair_grads: contrastive_loss of frl/losses/contrastive.py:29-212 over T pairs SORTED by anchor
+ * (pairs [T][2] int64 rows of emb [.][D] f32, weights [T] or NULL, is_pos [T] bytes, seg [nseg+1] segment bounds; similarity 0 = l2
+ * (-|a-b|^2/D), 1 = cosine, 2 = dot): per-anchor loss_a = -log(sum_pos + 1e-8) + log(sum_all + 1e-8) relative to the anchor's largest
+ * logit, loss[0] = mean; coef[p] = d loss_a / d logit_p; the gradient rows ga / gb [T][D] carry gscale[0] / (nseg * temperature). */
+int frl_gather_locations_fwd(const void* feat, int64_t sC, int64_t sH, int64_t sW, int C, int H, int W, const int64_t* coords, int64_t N,
+                             void* out, int dtype, frl_stream_t stream);
+int frl_segment_sum_rows(const float* vals, const int64_t* order, const int64_t* keys_sorted, int64_t M, int D, float* out, int64_t out_stride,
+                         int accumulate, frl_stream_t stream);
+int frl_infonce_fwd(const float* emb, int D, const int64_t* pairs, const float* weights, const unsigned char* is_pos, int64_t T,
+                    const int64_t* seg, int64_t nseg, float temperature, int similarity, float* sims, float* logits, float* loss_a, float* coef,
+                    float* loss, frl_stream_t stream);
+int frl_infonce_pair_grads(const float* emb, int D, const int64_t* pairs, const float* sims, const float* coef, const float* gscale, int64_t T,
+                           int64_t nseg, float temperature, int similarity, float* ga, float* gb, frl_stream_t stream);
 
 /* ---- mutual k-nearest-neighbour pair mining -----------------------------------------------------
  * frl/losses/pairs.py:531-610 pairs_mutual_knn_chunked: per anchor the k nearest anchors by L2 distance in feature space, excluding

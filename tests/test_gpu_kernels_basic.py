@@ -110,6 +110,38 @@ def test_vq_assign_bit_exact(dtype, N, K, d, ties):
     perp = torch.exp(-(p * torch.log(p + 1e-10)).sum()).item()
     assert abs(stats[1].item() - perp) <= 1e-4 * perp
     assert stats[2].item() < 0.05 * N + 8  # few rows needed the float64 path
+    prep = ops.vq_prepare(et.to(dev), N, dtype)                           # prepared codebook image: identical results, bit for bit
+    for _ in range(2):                                                   # (twice: the workspace header is re-armed every call)
+        idx2, zq2, stats2, counts2 = ops.vq_assign(zt.to(dev), et.to(dev), prep)
+        assert torch.equal(idx2.cpu().long(), idx_ref) and torch.equal(zq2, zq) and torch.equal(counts2, counts)
+        assert torch.equal(stats2, stats)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,K,d,dup", [(66000, 512, 64, 2), (4096, 512, 64, 2), (3000, 64, 64, 64), (70000, 256, 32, 4), (2048, 1024, 64, 2)])
+def test_vq_assign_every_row_is_a_tie(dtype, N, K, d, dup):
+    """Worst case of the exact re-evaluation: the codebook holds every vector `dup` times, so EVERY row ties between `dup` codes
+    (dup = K: all codes identical) -- the first index must win everywhere.  Exercises the in-kernel list drain (far more parked rows
+    than the list holds), the pending-candidate flush (more than two candidates per lane) and, for K = 1024, the multi-chunk path.
+    Also checks that a prepared codebook image gives the same result as the one-call entry point."""
+    from frl_hip import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(N + K + dup)
+    base = torch.randn(K // dup, d, generator=g)
+    e = base.repeat_interleave(dup, dim=0).contiguous()                 # codes j*dup .. j*dup+dup-1 are identical
+    z = torch.randn(N, d, generator=g).to(dtype)
+    e_eff = e.to(dtype).float() if dtype == torch.bfloat16 else e
+    ref = torch.from_numpy(O.vq_argmin_np(z.float().numpy(), e_eff[::dup].contiguous().numpy())) * dup
+    idx, zq, stats, counts = ops.vq_assign(z.to(dev), e.to(dev))
+    assert torch.equal(idx.cpu().long(), ref), f"{(idx.cpu().long() != ref).sum().item()} mismatching indices"
+    assert torch.equal(zq.cpu(), e_eff[ref].to(dtype))
+    assert torch.equal(counts.cpu().long(), torch.bincount(ref, minlength=K))
+    assert stats[2].item() == N                                          # every row went through the float64 path
+    sq_ref = ((z.double() - e_eff[ref].double()) ** 2).sum().item()
+    assert abs(stats[0].item() - sq_ref) <= 1e-5 * sq_ref
+    prep = ops.vq_prepare(e.to(dev), N, dtype)
+    idx2, zq2, stats2, counts2 = ops.vq_assign(z.to(dev), e.to(dev), prep)
+    assert torch.equal(idx2, idx) and torch.equal(zq2, zq) and torch.equal(counts2, counts) and torch.equal(stats2, stats)
 
 
 def test_vq_golden_fixture(golden_dir):

@@ -284,6 +284,42 @@ def test_nonfinite_batch_leaves_ema_and_codebook_manager_untouched():
     assert not torch.equal(m.quant.codebook.detach(), cb1) and int(mgr.window.sum()) == 2 * 8 * 8
 
 
+def test_graph_captured_step_reproduces_the_eager_trajectory(golden_dir):
+    """VQVAETrainer.step_graphed replays the whole step (both streams of the forward, autograd backward, clip + AdamW, codebook
+    hooks) from a captured hipGraph.  Same kernels on the same inputs: parameters after a run that mixes good batches, a
+    non-finite batch (skipped by the device flag inside the graph) and a per-step cosine learning rate (device word) must EQUAL
+    those of the eager trainer, and capturing must not consume optimizer steps."""
+    from frl_hip.training.codebook_manager import CodebookManager
+    from frl_hip.training.trainer import VQVAETrainer
+    fx = _load(golden_dir, "vqvae_tiny_seed0")
+    tiles = [t.contiguous() for t in torch.from_numpy(fx["tiles"]).float().to(DEV)]
+    bad = tiles[1].clone()
+    bad[0, 0, 0, 0, 0] = float("nan")
+    seq = [tiles[0], tiles[1], bad, tiles[2], tiles[0], tiles[1]]
+
+    def run(graphed):
+        m = _vqvae_from_fixture(fx)
+        m.attach_codebook_manager(CodebookManager(num_codes=16, code_dim=8, reset_every=4, min_count=1))
+        tr = VQVAETrainer(m, lr=1e-3, total_steps=8)
+        losses = []
+        for t in seq:
+            out = tr.step_graphed(t) if graphed else tr.step(t)
+            losses.append(float(out["loss"].detach()))
+        torch.cuda.synchronize()
+        return m, tr, losses
+
+    m0, tr0, l0 = run(False)
+    m1, tr1, l1 = run(True)
+    assert tr1.graph_supported() and len(tr1._graphs) == 4                      # one graph per distinct input buffer
+    assert tr0.opt.applied_and_skipped == tr1.opt.applied_and_skipped == (5, 1)
+    assert np.isnan(l1[2]) and np.isnan(l0[2])
+    assert [a for a in l0 if a == a] == [a for a in l1 if a == a]
+    for (n, p), (_, q) in zip(m0.named_parameters(), m1.named_parameters()):
+        assert torch.equal(p, q), n
+    assert torch.equal(m0.codebook_manager.window, m1.codebook_manager.window)
+    assert int(m0.codebook_manager.revived.item()) == int(m1.codebook_manager.revived.item())
+
+
 def test_configs1_train_step_end_to_end():
     """BASELINE configs[1] as bench.py measures it (256 tiles of 5x32x32x64, K = 512, d = 64, bf16): one full train step through the
     HIP path -- VQ indices are the exact float64 argmin of the latents the encoder produced, every loss term is finite, parameters move."""

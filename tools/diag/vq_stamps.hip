@@ -25,9 +25,9 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); printf("iter %d rc=%d %.1f us (whole frl_vq_assign_fwd)\n", it, rc, ms * 1e3f);
   }
   std::vector<unsigned long long> h(512 * 128); CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-  const char* nm[6] = {"z load + norms", "batch bias (3 barriers)", "chunk/en fill (2 barriers)", "main loop", "epilogue", "tail"};
+  const char* nm[7] = {"z load + norms", "batch bias (3 barriers)", "chunk/en fill (2 barriers)", "main loop", "epilogue", "exact re-evaluation (fused)", "partials, atomics, ticket, statistics"};
   double tot = 0;
-  for (int ph = 0; ph < 6; ++ph) { double s = 0; int nz = 0; for (int b = 0; b < 512; ++b) for (int w = 0; w < 16; ++w) { const double v = (double)h[(size_t)b * 128 + w * 8 + ph]; s += v; nz += h[(size_t)b * 128 + w * 8 + 3] != 0; } s /= nz; tot += s; printf("phase %d %-28s %9.0f cycles per wave (whole kernel)\n", ph, nm[ph], s); }
+  for (int ph = 0; ph < 7; ++ph) { double s = 0; int nz = 0; for (int b = 0; b < 512; ++b) for (int w = 0; w < 16; ++w) { const double v = (double)h[(size_t)b * 128 + w * 8 + ph]; s += v; nz += h[(size_t)b * 128 + w * 8 + 3] != 0; } s /= nz; tot += s; printf("phase %d %-28s %9.0f cycles per wave (whole kernel)\n", ph, nm[ph], s); }
   printf("total %.0f cycles per wave\n", tot);
   return 0;
 }

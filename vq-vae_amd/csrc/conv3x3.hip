@@ -521,7 +521,7 @@ static int launch_c3(const void* x, const void* xm, int mask_act, const float* w
   FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int tiles = B * ((H + C3F_TH - 1) / C3F_TH) * ((W + C3_TW - 1) / C3_TW);
   const int grid = tiles < 256 ? tiles : 256;                  // LDS allows one workgroup per CU: persistent over the tiles
-  FRL_LAUNCH(kern, dim3(grid), dim3(512), lds, st, (const T*)x, (const T*)xm, mask_act, (const frag_t*)ws, bias, (T*)y, B,
+  FRL_LAUNCH_AS("conv3x3_kernel", kern, dim3(grid), dim3(512), lds, st, (const T*)x, (const T*)xm, mask_act, (const frag_t*)ws, bias, (T*)y, B,
                      H, W, Cin, Cout, act);
   return frl_check_launch("conv3x3");
 }
@@ -580,13 +580,13 @@ int frl_conv3x3_bwd_weight(const void* dy, const void* y, int act, const void* x
       const size_t lds = ((size_t)256 * (64 + 4) + (size_t)18 * 18 * (32 + 4)) * 4;
       auto kern = conv3x3_wgrad_kernel<float, 2, 1, 8>;
       FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      FRL_LAUNCH(kern, dim3(nwg), dim3(512), lds, stream, (const float*)dy, (const float*)ym, act, (const float*)x, (float*)ws,
+      FRL_LAUNCH_AS("conv3x3_wgrad_kernel", kern, dim3(nwg), dim3(512), lds, stream, (const float*)dy, (const float*)ym, act, (const float*)x, (float*)ws,
                          B, H, W, Cin, Cout, oc_base, tpw, 0);
     } else if (dtype == FRL_BF16) {
       const size_t lds = ((size_t)256 * (64 + 8) + (size_t)18 * 18 * (64 + 8)) * 2;
       auto kern = conv3x3_wgrad_kernel<bf16, 4, 2, 8>;
       FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      FRL_LAUNCH(kern, dim3(nwg), dim3(512), lds, stream, (const bf16*)dy, (const bf16*)ym, act, (const bf16*)x, (float*)ws, B,
+      FRL_LAUNCH_AS("conv3x3_wgrad_kernel", kern, dim3(nwg), dim3(512), lds, stream, (const bf16*)dy, (const bf16*)ym, act, (const bf16*)x, (float*)ws, B,
                          H, W, Cin, Cout, oc_base, tpw, (flags & 1) ? 0 : 1);
     } else return frl_fail(-2, "conv3x3_bwd_weight: bad dtype");
     launch_slab_reduce<float, C3Epi>((const float*)ws, nwg, slab_n, C3Epi{64, Cin * 9, oc_base, Cout, dw, dbias}, stream);

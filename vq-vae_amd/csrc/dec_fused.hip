@@ -322,7 +322,7 @@ static int launch_dec_bwd(const void* z, const float* w1, const float* b1, const
                      (size_t)R * ((DF_F + 8) + 2 * (DF_H + 8) + (CZP + 8)) * sizeof(TT);
   auto kern = dec_mse_bwd_kernel<NFZ, NW>;
   FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  FRL_LAUNCH(kern, dim3(grid), dim3(64 * NW), lds, st, (const TT*)z, (const frag8*)pk, b1, b2, (const TT*)tgt, mask, gscale, stats, (TT*)dz, P, Cz,
+  FRL_LAUNCH_AS("dec_mse_bwd_kernel", kern, dim3(grid), dim3(64 * NW), lds, st, (const TT*)z, (const frag8*)pk, b1, b2, (const TT*)tgt, mask, gscale, stats, (TT*)dz, P, Cz,
              (float*)ws);
   launch_slab_reduce<float, DecEpi<NFZ>>((const float*)ws, (int)grid, (int64_t)slab_n, DecEpi<NFZ>{dw2, dw1, db2, db1, Cz}, st);
   return frl_check_launch("decoder_mse_bwd");

@@ -18,11 +18,23 @@ void frl_timing_begin(const char* kernel, hipStream_t st);
 void frl_timing_end(hipStream_t st);
 #define FRL_ARG1_(a, ...) a
 #define FRL_ARG5_(a, b, c, d, e, ...) e
-#define FRL_STR_(...) #__VA_ARGS__
+#define FRL_STR2_(...) #__VA_ARGS__
+#define FRL_STR_(...) FRL_STR2_(__VA_ARGS__)
 #define FRL_LAUNCH(...)                                                     \
   do {                                                                      \
     (void)hipGetLastError();                                                \
     if (g_frl_timing) frl_timing_begin(FRL_STR_(FRL_ARG1_(__VA_ARGS__)), FRL_ARG5_(__VA_ARGS__)); \
+    hipLaunchKernelGGL(__VA_ARGS__);                                        \
+    if (g_frl_timing) frl_timing_end(FRL_ARG5_(__VA_ARGS__));               \
+    hipError_t _le = hipGetLastError();                                     \
+    if (_le != hipSuccess && g_frl_pending == hipSuccess) g_frl_pending = _le; \
+  } while (0)
+
+// same with an explicit timing name (for launches through a function-pointer variable)
+#define FRL_LAUNCH_AS(name, ...)                                            \
+  do {                                                                      \
+    (void)hipGetLastError();                                                \
+    if (g_frl_timing) frl_timing_begin(name, FRL_ARG5_(__VA_ARGS__));       \
     hipLaunchKernelGGL(__VA_ARGS__);                                        \
     if (g_frl_timing) frl_timing_end(FRL_ARG5_(__VA_ARGS__));               \
     hipError_t _le = hipGetLastError();                                     \

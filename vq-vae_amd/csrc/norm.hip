@@ -204,7 +204,7 @@ static int gn_fwd_impl(const void* x, const float* gamma, const float* beta, voi
   {
     auto kern = gn_reduce_kernel<T, V, 0, NTH>;
     if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    FRL_LAUNCH(kern, dim3(B), dim3(NTH), lds, st, (const T*)x, (const T*)nullptr, gamma, beta,
+    FRL_LAUNCH_AS("gn_reduce_kernel(fwd)", kern, dim3(B), dim3(NTH), lds, st, (const T*)x, (const T*)nullptr, gamma, beta,
                (const float*)nullptr, (const float*)nullptr, HW, C, G, eps, 0, mean, rstd, (float*)nullptr);
   }
   const int rpw = gn_rows_per_wg(B, HW, rpi);
@@ -227,7 +227,7 @@ static int gn_bwd_impl(const void* dy, const void* x, const float* gamma, const 
   {
     auto kern = gn_reduce_kernel<T, V, 1, NTH>;
     if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    FRL_LAUNCH(kern, dim3(B), dim3(NTH), lds, st, (const T*)x, (const T*)dy, gamma, beta, mean, rstd, HW, C, G, 0.f, relu, sdy, sdyx, grp);
+    FRL_LAUNCH_AS("gn_reduce_kernel(bwd)", kern, dim3(B), dim3(NTH), lds, st, (const T*)x, (const T*)dy, gamma, beta, mean, rstd, HW, C, G, 0.f, relu, sdy, sdyx, grp);
   }
   const int rpw = gn_rows_per_wg(B, HW, rpi);
   FRL_LAUNCH((gn_bwd_apply_kernel<T, V>), dim3((unsigned)((HW + rpw - 1) / rpw), (unsigned)B), dim3(256), 0, st, (const T*)x, (const T*)dy,

@@ -52,8 +52,9 @@ __global__ __launch_bounds__(256) void frl_adamw_kernel(const FrlParamBatch tab,
                                                         const double* __restrict__ partial, int npartial, float max_norm, float lr,
                                                         double beta1d, double beta2d, float eps, int step_host,
                                                         float* __restrict__ norm_out, const float* __restrict__ ok, int* counters,
-                                                        int last_batch) {
+                                                        int last_batch, const float* __restrict__ lr_dev) {
   __shared__ float coef_s;
+  if (lr_dev != nullptr) lr = lr_dev[0];                     // learning rate kept on the device (a captured graph replays with new values)
   const bool go = (ok == nullptr) || (ok[0] > 0.f);
   // update number: device counter + 1 when the caller keeps one (exact under skipped batches), else the host's count
   const int step = (counters != nullptr) ? counters[0] + 1 : step_host;
@@ -159,7 +160,7 @@ size_t frl_adamw_workspace_bytes(void) { return 4096 * sizeof(double); }
 // norm_out (device, optional) receives the pre-clip global gradient norm.  max_norm <= 0 disables clipping.
 int frl_adamw_clip_step(const void* desc_host, int ntensors, const void* chunks, const int* chunk_tensor, int nchunks, float max_norm,
                         float lr, double beta1, double beta2, float eps, int step, float* norm_out, const float* ok, int* counters,
-                        void* ws, size_t ws_bytes, hipStream_t stream) {
+                        const float* lr_dev, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (ntensors <= 0 || nchunks <= 0) return frl_fail(-2, "adamw: empty parameter table");
   if (step < 1 && counters == nullptr) return frl_fail(-2, "adamw: step must be >= 1");
   if (ws == nullptr || ws_bytes < frl_adamw_workspace_bytes()) return frl_fail(-4, "adamw: workspace too small");
@@ -182,7 +183,7 @@ int frl_adamw_clip_step(const void* desc_host, int ntensors, const void* chunks,
           poff += grid;
         } else {
           FRL_LAUNCH(frl_adamw_kernel, dim3(grid), dim3(256), 0, stream, tab, t0, (const int2*)chunks + c0, c1 - c0, (const double*)partial,
-                     npartial, max_norm, lr, beta1, beta2, eps, step, norm_out, ok, counters, (t0 + OPT_BATCH >= ntensors) ? 1 : 0);
+                     npartial, max_norm, lr, beta1, beta2, eps, step, norm_out, ok, counters, (t0 + OPT_BATCH >= ntensors) ? 1 : 0, lr_dev);
         }
       }
       c0 = c1;

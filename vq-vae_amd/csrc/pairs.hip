@@ -148,7 +148,7 @@ static int knn_launch(const float* feat, int N, int D, const int32_t* patch_id, 
                       int32_t* knn_idx, size_t lds, hipStream_t stream) {
   auto kern = knn_kernel<D4PT>;
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  FRL_LAUNCH(kern, dim3((N + KNN_WAVES - 1) / KNN_WAVES), dim3(64 * KNN_WAVES), lds, stream, feat, N, D, patch_id, coords, pos_min_spatial,
+  FRL_LAUNCH_AS("knn_kernel", kern, dim3((N + KNN_WAVES - 1) / KNN_WAVES), dim3(64 * KNN_WAVES), lds, stream, feat, N, D, patch_id, coords, pos_min_spatial,
              k, knn_idx);
   return 0;
 }

@@ -138,7 +138,7 @@ static int launch_pw(const void* x, const void* xmask, int mask_act, const float
   int64_t grid = (ngroups + 3) / 4;
   if (grid > 4096) grid = 4096;
   if (grid < 1) grid = 1;
-  FRL_LAUNCH(kern, dim3((unsigned)grid), dim3(256), lds, st, (const T*)x, (const T*)xmask, mask_act,
+  FRL_LAUNCH_AS("pw_conv_kernel", kern, dim3((unsigned)grid), dim3(256), lds, st, (const T*)x, (const T*)xmask, mask_act,
              (const frag_t*)ws, bias, (T*)y, P, Cin, Cout, act);
   return frl_check_launch("pw_conv");
 }

@@ -262,7 +262,7 @@ static int launch_wgrad(const void* dy, const void* ymask, int mask_act, const v
   const size_t lds = (size_t)WG_KP * ((OBW * 64 + 8) + (IB * 16 + 8)) * sizeof(T);
   auto kern = pw_wgrad_kernel<T, OBW, IB>;
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  FRL_LAUNCH(kern, dim3(nwg), dim3(256), lds, st, (const T*)dy, (const T*)ymask, mask_act, (const T*)x, ws,
+  FRL_LAUNCH_AS("pw_wgrad_kernel", kern, dim3(nwg), dim3(256), lds, st, (const T*)dy, (const T*)ymask, mask_act, (const T*)x, ws,
                      P, Cout, Cin, rows, HW, Tn, toff, use_tr, ldy);
   return frl_check_launch("pw_wgrad");
 }

@@ -214,7 +214,7 @@ static int launch_tcn_bwd_tp(const void* x, const void* dy, const void* pk, cons
   if constexpr (tcn_tp_ok_b<T, NFI, TP>()) {
     auto kern = tcn_block_bwd_kernel<T, NFI, MBO, TP, DIL>;
     if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    FRL_LAUNCH(kern, dim3(grid), dim3(256), lds, st, (const T*)x, (const T*)dy, (const frag_t*)pk, bc, gw, gb, bg, wp ? 1 : 0, bp,
+    FRL_LAUNCH_AS("tcn_bwd_kernel", kern, dim3(grid), dim3(256), lds, st, (const T*)x, (const T*)dy, (const frag_t*)pk, bc, gw, gb, bg, wp ? 1 : 0, bp,
                (T*)dconv, (T*)dgpre, (T*)normed, (T*)dres, ws, a);
     return 0;
   } else {

@@ -173,7 +173,7 @@ static int launch_tcn_fwd_tp(const void* x, const float* bc, const float* gw, co
   if constexpr (tcn_tp_ok<T, NFI, TP>()) {
     auto kern = tcn_block_fwd_kernel<T, NFI, MBO, TP, DIL>;
     if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    FRL_LAUNCH(kern, dim3(tcn_grid(a.npix)), dim3(256), lds, st, (const T*)x, (const frag_t*)ws, bc, gw, gb, bg, wp ? 1 : 0, bp, (T*)y, a);
+    FRL_LAUNCH_AS("tcn_fwd_kernel", kern, dim3(tcn_grid(a.npix)), dim3(256), lds, st, (const T*)x, (const frag_t*)ws, bc, gw, gb, bg, wp ? 1 : 0, bp, (T*)y, a);
     return frl_check_launch("tcn_block_fwd");
   } else {
     return launch_tcn_fwd_tp<T, NFI, MBO, 0, 0>(x, bc, gw, gb, bg, wp, bp, y, a, ws, lds, st);
@@ -203,7 +203,7 @@ static int launch_tconv3_tp(const void* x, const void* r, const void* r2, const 
   if constexpr (tcn_tp_ok<T, NFI, TP>()) {
     auto kern = tconv3_kernel<T, NFI, MBO, NFP, TP, DIL>;
     if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    FRL_LAUNCH(kern, dim3(tcn_grid(a.npix)), dim3(256), lds, st, (const T*)x, (const frag_t*)ws, (const T*)r, (const T*)r2, wp ? 1 : 0,
+    FRL_LAUNCH_AS("tconv3_kernel", kern, dim3(tcn_grid(a.npix)), dim3(256), lds, st, (const T*)x, (const frag_t*)ws, (const T*)r, (const T*)r2, wp ? 1 : 0,
                Cp, (T*)y, a);
     return frl_check_launch("tconv3");
   } else {

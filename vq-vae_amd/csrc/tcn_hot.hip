@@ -626,12 +626,12 @@ static int th_launch_bwd(const void* x, const void* mask, const void* dy, const 
   if (mask != nullptr) {
     auto kern = tcn_hot_bwd2_kernel<DIL, true>;
     FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TH_BWD_LDS));
-    FRL_LAUNCH(kern, dim3(grid), dim3(512), TH_BWD_LDS, st, (const bf16*)x, (const bf16*)mask, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx,
+    FRL_LAUNCH_AS("tcn_hot_bwd2_kernel", kern, dim3(grid), dim3(512), TH_BWD_LDS, st, (const bf16*)x, (const bf16*)mask, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx,
                slab, npix, HW, eps);
   } else {
     auto kern = tcn_hot_bwd2_kernel<DIL, false>;
     FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TH_BWD_LDS));
-    FRL_LAUNCH(kern, dim3(grid), dim3(512), TH_BWD_LDS, st, (const bf16*)x, (const bf16*)nullptr, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx,
+    FRL_LAUNCH_AS("tcn_hot_bwd2_kernel", kern, dim3(grid), dim3(512), TH_BWD_LDS, st, (const bf16*)x, (const bf16*)nullptr, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx,
                slab, npix, HW, eps);
   }
   return 0;

@@ -503,7 +503,7 @@ static void b3_launch(const void* x, const void* dy, const frag8* pk, const floa
                       float* slab, unsigned grid, int ntile, int HW, float eps, hipStream_t st) {
   auto kern = tcn_hot_bwd3_kernel<DIL>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_LDS);
-  FRL_LAUNCH(kern, dim3(grid), dim3(512), B3_LDS, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx, slab, ntile, HW, eps);
+  FRL_LAUNCH_AS("tcn_hot_bwd3_kernel", kern, dim3(grid), dim3(512), B3_LDS, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx, slab, ntile, HW, eps);
 }
 
 int th_bwd3_launch(int dilation, const void* x, const void* dy, const frag8* pk, const float* bc, const float* gw, const float* gb, const float* bg,

@@ -25,33 +25,34 @@
 #define VQ_MAX_CHUNK 512
 
 struct VqHeader {           // lives at the start of the workspace (zeroed by hipMemsetAsync every call)
-  unsigned enmax_bits;      // max_k ||e_k||^2 as f32 bits (atomicMax on positive floats)
-  int namb;                 // number of rows flagged for exact re-evaluation (append counter of amb_list)
-  double sq_fix;            // sum of squared errors of the re-evaluated rows
+  unsigned enmax_bits;      // max_k ||e_k||^2 as f32 bits (atomicMax on positive floats; multi-chunk path)
+  int namb;                 // number of rows flagged for exact re-evaluation (append counter of amb_list / total of the fused path)
+  double sq_fix;            // sum of squared errors of the re-evaluated rows (multi-chunk path)
+  int done;                 // fused path: workgroups that have published their partial results (arrival ticket)
+  int pad;
 };
 
-// ---------------------------------------------------------------------------------------------
-// prep: en[k] = ||round_T(e_k)||^2 (f32), enmax
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void vq_prep_kernel(const float* __restrict__ E, int K, int d, float* __restrict__ en, VqHeader* hdr) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= K) return;
-  float s = 0.f;
-  for (int j = 0; j < d; ++j) {
-    const float v = to_f32(from_f32<T>(E[(int64_t)k * d + j]));
-    s = fmaf(v, v, s);
-  }
-  en[k] = s;
-  atomicMax(&hdr->enmax_bits, __float_as_uint(s));
-}
-
-// packed MFMA A-fragment image of -2 * round_T(E): frag index (mb * NF + s) * 64 + lane, code = 16*mb + (lane & 15),
-// channel = q*(lane >> 4) + s*FE + e.  Written once per call; workgroups copy their chunk with 16-byte loads.
+// prep + pack in ONE launch (blocks [0, npack) write fragments, the rest the norms): the "prepared codebook" image
+// [en: kpad floats][packed fragments] that frl_vq_prepare hands to the caller, who keeps it until the codebook changes
 template <typename T, int NF>
-__global__ void vq_pack_kernel(const float* __restrict__ E, int K, int d, typename DT<T>::frag_t* __restrict__ pk, int total) {
+__global__ void vq_prepare_kernel(const float* __restrict__ E, int K, int d, float* __restrict__ en, int kpad,
+                                  typename DT<T>::frag_t* __restrict__ pk, int total, int npack_blocks) {
   constexpr int FE = DT<T>::FE;
   constexpr int q = NF * FE;
+  if ((int)blockIdx.x >= npack_blocks) {
+    const int k = ((int)blockIdx.x - npack_blocks) * blockDim.x + threadIdx.x;
+    if (k >= kpad) return;
+    float s = 3.0e38f;                                     // codes beyond K never win
+    if (k < K) {
+      s = 0.f;
+      for (int j = 0; j < d; ++j) {
+        const float v = to_f32(from_f32<T>(E[(int64_t)k * d + j]));
+        s = fmaf(v, v, s);
+      }
+    }
+    en[k] = s;
+    return;
+  }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int ln = i & 63, fs = i >> 6;
@@ -79,12 +80,66 @@ __global__ void vq_pack_kernel(const float* __restrict__ E, int K, int d, typena
 #ifdef VQ_STAMPS
 __device__ unsigned long long* vq_dbg;      // diagnostic build only (tools/diag/vq_stamps.hip)
 #endif
-template <typename T, int NF, int NT, int NW>
+// exact squared distances of row n to the codes k0 and k1 (k1 < 0: only k0) in float64; operands rounded to T first, as everywhere
+// in this file.  16-byte loads, four chunks in flight: the caller is one lane per candidate pair, the latency of the loads is all
+// there is to hide.
+template <typename T>
+__device__ __forceinline__ void vq_exact_pair(const T* __restrict__ Z, const float* __restrict__ E, int64_t n, int k0, int k1, int d,
+                                              double& d0, double& d1) {
+  const T* zr = Z + n * (int64_t)d;
+  const float* e0 = E + (int64_t)k0 * d;
+  const float* e1 = E + (int64_t)(k1 >= 0 ? k1 : k0) * d;
+  double s0 = 0.0, s1 = 0.0;
+  if ((d & 7) == 0) {
+#pragma unroll 4
+    for (int j = 0; j < d; j += 8) {
+      float zv[8];
+      if constexpr (sizeof(T) == 2) {
+        Vec<T>::load(zr + j, zv);
+      } else {
+        Vec<T>::load(zr + j, zv);
+        Vec<T>::load(zr + j + 4, zv + 4);
+      }
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(e0 + j), a1 = *reinterpret_cast<const f32x4*>(e0 + j + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(e1 + j), b1 = *reinterpret_cast<const f32x4*>(e1 + j + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const double zz = (double)zv[e];
+        const double da = zz - (double)to_f32(from_f32<T>(e < 4 ? a0[e & 3] : a1[e & 3]));
+        const double db = zz - (double)to_f32(from_f32<T>(e < 4 ? b0[e & 3] : b1[e & 3]));
+        s0 += da * da;
+        s1 += db * db;
+      }
+    }
+  } else {
+    for (int j = 0; j < d; ++j) {
+      const double zz = (double)to_f32(zr[j]);
+      const double da = zz - (double)to_f32(from_f32<T>(e0[j])), db = zz - (double)to_f32(from_f32<T>(e1[j]));
+      s0 += da * da;
+      s1 += db * db;
+    }
+  }
+  d0 = s0;
+  d1 = s1;
+}
+
+#define VQ_AMB_CAP 512      // fused path: capacity of the workgroup's list of rows awaiting the exact re-evaluation (3 ints per row)
+
+// FUSED (single codebook chunk: the whole codebook stays in LDS): ONE launch does everything --
+//   * rows whose two best scores are within the rounding bound are parked in an LDS list and resolved by the workgroup itself while the
+//     codebook is still resident (vq_resolve below: candidates screened on the matrix cores, float64 only for the candidates);
+//   * the code histogram goes from LDS into the global counts with one integer atomic per (workgroup, used code) (integer sums are
+//     order-independent, so the result is still bit-reproducible);
+//   * the workgroup that arrives last (ticket counter behind an agent-scope release / acquire) folds the squared-error partials and
+//     the perplexity and writes stats / counts.
+// The multi-chunk path (K larger than one LDS chunk) keeps the global list + vq_fixup kernels + slab reduction.
+template <typename T, int NF, int NT, int NW, bool FUSED>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
     const T* __restrict__ Z, const float* __restrict__ E, const float* __restrict__ en_g, const VqHeader* __restrict__ hdr,
     int64_t N, int K, int d, int Kc, int32_t* __restrict__ idx_out, T* __restrict__ zq_out,
-    float* __restrict__ partial /*[grid*4]*/, int32_t* __restrict__ hist_slab /*[grid][K]*/, VqHeader* __restrict__ hdr_w,
-    int32_t* __restrict__ amb_list, const typename DT<T>::frag_t* __restrict__ pk) {
+    float* __restrict__ partial /*[grid*NW]*/, int32_t* __restrict__ hist_slab /*[grid][K]*/, VqHeader* __restrict__ hdr_w,
+    int32_t* __restrict__ amb_list, const typename DT<T>::frag_t* __restrict__ pk,
+    int32_t* __restrict__ counts_acc, int32_t* __restrict__ counts_out, float* __restrict__ stats_out) {
   typedef typename DT<T>::frag_t frag_t;
   constexpr int FE = DT<T>::FE;
   constexpr int q = NF * FE;                 // channels per lane quarter
@@ -92,12 +147,31 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
   frag_t* wl = reinterpret_cast<frag_t*>(smem);                       // [Kc/16][NF][64]
   float* enl = reinterpret_cast<float*>(smem + (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t));  // [Kc]
   int* hist = reinterpret_cast<int*>(enl + Kc);                        // [K]
-  unsigned* cbw = reinterpret_cast<unsigned*>(hist + K);               // batch maximum of ||z||^2 (f32 bits)
+  unsigned* cbw = reinterpret_cast<unsigned*>(hist + K);               // batch maximum of ||z||^2 (f32 bits), [NW + 1] (+ pad to 32)
+  float* enr = reinterpret_cast<float*>(cbw + 32);                     // FUSED: [Kc] ||e||^2 without the batch bias
+  int* amb_rows = reinterpret_cast<int*>(enr + Kc);                    // FUSED: [VQ_AMB_CAP] x {row low, row high, candidate limit (f32 bits)}
+  int* amb_n = amb_rows + 3 * VQ_AMB_CAP;                              // FUSED: [0] list length, [1] broadcast slot
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vx = lane & 15, kc = lane >> 4;
   const int nchunks = (K + Kc - 1) / Kc;
   const bool fast = (d == 4 * q);
-  const float enmax = __uint_as_float(hdr->enmax_bits);
+  float enmax;
+  if constexpr (FUSED) {                                               // max ||e||^2 over the real codes, by the workgroup itself
+    float m = 0.f;
+    for (int k = tid; k < K; k += NW * 64) m = fmaxf(m, en_g[k]);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) cbw[wave] = __float_as_uint(m);
+    if (tid == 0) { amb_n[0] = 0; amb_n[1] = 0; }
+    __syncthreads();
+    unsigned mm = 0u;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) mm = mm > cbw[w] ? mm : cbw[w];
+    enmax = __uint_as_float(mm);
+    __syncthreads();
+  } else {
+    enmax = __uint_as_float(hdr->enmax_bits);
+  }
   const float err_rel = (float)(4 * q + 8) * 1.1920929e-7f;            // (d_pad+8) * 2^-23: f32 accumulation of exact products
   const float thr_rel = 3.0517578125e-5f + 2.f * err_rel;              // 2^-(22-7) key truncation of both scores + 2*err
 
@@ -112,6 +186,79 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
   for (int k = tid; k < K; k += NW * 64) hist[k] = 0;
   float sq_acc = 0.f;
   int filled_chunk = -1;
+
+  // ---- FUSED: exact re-evaluation of the parked rows by the workgroup itself (the whole codebook is resident: Kc >= K).
+  // One wave per tile of 16 parked rows: pass 1 finds the smallest f32 score of every row on the matrix cores, pass 2 re-scores and
+  // keeps every code within the rounding bound of it (the float64 arg-min is provably among them); those few candidates are
+  // evaluated in float64 (up to two pending per lane, flushed together so that the 64-element loops of all lanes run side by side);
+  // first index wins ties.  Then z_q, the squared error and the histogram of these rows are written like those of the main path.
+  int n_resolved = 0;
+  auto resolve = [&]() {
+    if constexpr (FUSED) {
+      const int n = amb_n[0];
+      const int nmb = Kc / 16;
+      for (int t0 = wave * 16; t0 < n; t0 += NW * 16) {
+        const int li = t0 + vx;
+        const bool valid = li < n;
+        const int* ent = amb_rows + 3 * (valid ? li : t0);
+        const int64_t row = ((int64_t)(unsigned)ent[1] << 32) | (unsigned)ent[0];
+        // every code whose (bias-free) f32 score is <= lim may be the float64 arg-min; lim was fixed by the main pass from the row's
+        // best key, the key truncation and the rounding bound of both passes
+        const float lim = __int_as_float(ent[2]);
+        LQTile<T, NF> zr;
+        lq_load<T, NF>(zr, Z, row, d, kc, fast);
+        double best = 1.0e300;
+        int bestk = 0x7fffffff, p0 = -1, p1 = -1;
+        auto flush = [&]() {
+          if (p0 >= 0) {
+            double d0, d1;
+            vq_exact_pair<T>(Z, E, row, p0, p1, d, d0, d1);
+            if (d0 < best || (d0 == best && p0 < bestk)) { best = d0; bestk = p0; }
+            if (p1 >= 0 && (d1 < best || (d1 == best && p1 < bestk))) { best = d1; bestk = p1; }
+          }
+          p0 = p1 = -1;
+        };
+#pragma unroll 4
+        for (int mb = 0; mb < nmb; ++mb) {
+          f32x4 acc = *reinterpret_cast<const f32x4*>(enr + mb * 16 + 4 * kc);
+#pragma unroll
+          for (int s = 0; s < NF; ++s) acc = mfma16(wl[(mb * NF + s) * 64 + lane], zr.f[s], acc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int code = mb * 16 + 4 * kc + r;
+            const bool hit = acc[r] <= lim && code < K;
+            if (__builtin_amdgcn_ballot_w64(hit && p1 >= 0) != 0ull) flush();       // a lane with both slots taken: evaluate all pending
+            if (hit) { if (p0 < 0) p0 = code; else p1 = code; }
+          }
+        }
+        flush();
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+          const double ob = __shfl_xor(best, off, 64);
+          const int okk = __shfl_xor(bestk, off, 64);
+          if (ob < best || (ob == best && okk < bestk)) { best = ob; bestk = okk; }
+        }
+        if (valid) {
+          const float* er = E + (int64_t)bestk * d + q * kc;
+          T* zo = zq_out + row * (int64_t)d + q * kc;
+#pragma unroll
+          for (int s = 0; s < NF * FE; ++s) {
+            if (q * kc + s < d) {
+              const float ev = to_f32(from_f32<T>(er[s]));
+              zo[s] = from_f32<T>(ev);
+              const float df = lq_get<T, NF>(zr, s / FE, s % FE) - ev;
+              sq_acc = fmaf(df, df, sq_acc);
+            }
+          }
+          if (kc == 0) { idx_out[row] = bestk; atomicAdd(&hist[bestk], 1); }
+        }
+      }
+      n_resolved += n;
+      __syncthreads();
+      if (tid == 0) amb_n[0] = 0;
+      __syncthreads();
+    }
+  };
 
   const int64_t vec_per_batch = NW * NT * 16;
   const int64_t nbatch = (N + vec_per_batch - 1) / vec_per_batch;
@@ -166,6 +313,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
         const int kbase = c * Kc;
         if (filled_chunk != c) copy_frags_lds<T>(wl, pk + (size_t)(kbase / 16) * NF * 64, (Kc / 16) * NF * 64, tid, NW * 64);
         for (int i = tid; i < Kc; i += NW * 64) enl[i] = (kbase + i < K) ? en_g[kbase + i] + Cb : 3.0e38f;
+        if constexpr (FUSED) {
+          if (filled_chunk != c)
+            for (int i = tid; i < Kc; i += NW * 64) enr[i] = (kbase + i < K) ? en_g[kbase + i] : 3.0e38f;
+        }
         __syncthreads();
         filled_chunk = c;
       }
@@ -226,7 +377,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
       if (row < N) {
         if (kc == 0) {
           idx_out[row] = amb ? (-1 - code) : code;
-          if (amb) amb_list[atomicAdd(&hdr_w->namb, 1)] = (int32_t)row;
+          if (amb) {
+            if constexpr (FUSED) {
+              const int pos = atomicAdd(&amb_n[0], 1);                 // < VQ_AMB_CAP: the list is drained before it can overflow
+              // s1 carries the batch bias Cb, the re-evaluation scores do not; thr[t] bounds key truncation + rounding of both
+              const float lim = (s1 - Cb) + thr[t] + 2.3841858e-7f * (s1 + Cb);
+              amb_rows[3 * pos] = (int)(unsigned)(row & 0xffffffffll);
+              amb_rows[3 * pos + 1] = (int)(row >> 32);
+              amb_rows[3 * pos + 2] = __float_as_int(lim);
+            } else {
+              amb_list[atomicAdd(&hdr_w->namb, 1)] = (int32_t)row;
+            }
+          }
         }
         if (!amb) {
           // gather z_q (rounded to T) for this lane's channel quarter, accumulate squared error
@@ -261,14 +423,68 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
       }
     }
     VQ_ST(4);                                                    // reduce, ambiguity test, z_q gather / store, histogram
+    if constexpr (FUSED) {                                       // (the tile registers are dead here: the drain costs no spill in the loop)
+      __syncthreads();
+      if (amb_n[0] > VQ_AMB_CAP - (int)vec_per_batch) resolve();  // (uniform) the list could overflow in the next batch: drain it now
+    }
   }
-  // ---- per-workgroup outputs: 4 wave partials of the squared error, histogram slab ----
+  if constexpr (FUSED) resolve();                                // (the loop ends behind a barrier)
+  VQ_ST(5);                                                      // fused: exact re-evaluation of the parked rows
+  // ---- per-workgroup outputs: wave partials of the squared error, histogram ----
   const float ws_ = wave_sum(sq_acc);
   if (lane == 0) partial[blockIdx.x * NW + wave] = ws_;
   __syncthreads();
-  for (int k = tid; k < K; k += NW * 64) hist_slab[(int64_t)blockIdx.x * K + k] = hist[k];
+  if constexpr (!FUSED) {
+    for (int k = tid; k < K; k += NW * 64) hist_slab[(int64_t)blockIdx.x * K + k] = hist[k];
+  } else {
+    for (int k = tid; k < K; k += NW * 64) {
+      const int h = hist[k];
+      if (h) atomicAdd(&counts_acc[k], h);                         // device-scope integer atomics: order-independent
+    }
+    if (tid == 0 && n_resolved) atomicAdd(&hdr_w->namb, n_resolved);
+    // publish (partials by plain stores, counts by atomics), then take a ticket; the last workgroup folds everything
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ticket = __hip_atomic_fetch_add(&hdr_w->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      amb_n[1] = (ticket == (int)gridDim.x - 1) ? 1 : 0;
+      if (ticket == (int)gridDim.x - 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    __syncthreads();
+    if (amb_n[1]) {
+      double* red = reinterpret_cast<double*>(smem);                // (the codebook fragments are no longer needed)
+      const int npartial = (int)gridDim.x * NW;
+      double sp = 0.0;
+      for (int i = tid; i < npartial; i += NW * 64) sp += (double)partial[i];
+      double hp = 0.0;
+      for (int k = tid; k < K; k += NW * 64) {
+        const int c = __hip_atomic_load(&counts_acc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        counts_out[k] = c;
+        const double p = (double)c / (double)N;
+        hp += p * log(p + 1e-10);
+      }
+      red[tid] = sp;
+      red[NW * 64 + tid] = hp;
+      __syncthreads();
+      for (int o = NW * 32; o > 0; o >>= 1) {
+        if (tid < o) { red[tid] += red[tid + o]; red[NW * 64 + tid] += red[NW * 64 + tid + o]; }
+        __syncthreads();
+      }
+      if (tid == 0) {
+        stats_out[0] = (float)red[0];
+        stats_out[1] = (float)exp(-red[NW * 64]);
+        stats_out[2] = (float)__hip_atomic_load(&hdr_w->namb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stats_out[3] = 0.f;
+      }
+    }
+  }
 #ifdef VQ_STAMPS
-  VQ_ST(5);
+  VQ_ST(6);                                                      // partials, histogram atomics, ticket, (last workgroup) statistics
   __syncthreads();
   if (tid < 128) vq_dbg[(size_t)blockIdx.x * 128 + tid] = (&vq_ts[0][0])[tid];
 #endif
@@ -791,51 +1007,80 @@ static int vq_grid(int64_t N, int d) {
 #define VQ_FIX_WAVES 1024
 #define VQ_BWD_WGS 256
 
-struct VqLayout { size_t hdr, en, counts_fix, partial, amb, hist, pack, total; int grid; };
+// "prepared codebook": [||e||^2: kpad floats (3e38 beyond K)][packed -2e fragments of kpad codes]; kpad = K rounded up to whole chunks
+struct VqPrep { size_t en, pack, total; int Kc, kpad, npk; };
+template <typename T, int NF>
+static VqPrep vq_prep_layout(int64_t N, int K, int d) {
+  VqPrep P;
+  const int d_pad = NF * DT<T>::FE * 4;
+  P.Kc = vq_chunk(K, d_pad, sizeof(T), vq_waves(N, d));
+  P.kpad = (K + P.Kc - 1) / P.Kc * P.Kc;
+  P.npk = (P.kpad / 16) * NF * 64;
+  P.en = 0;
+  P.pack = ((size_t)P.kpad * 4 + 255) / 256 * 256;
+  P.total = P.pack + (size_t)P.npk * sizeof(typename DT<T>::frag_t);
+  return P;
+}
+static size_t vq_prep_bytes_max(int K) { return ((size_t)(K + VQ_MAX_CHUNK) * 4 + 255) / 256 * 256 + (size_t)((K + 15) / 16 + 64) * 16 * 128 * 4; }
+
+struct VqLayout { size_t hdr, counts_fix, partial, amb, hist, prep, total; int grid; };
 static VqLayout vq_layout(int64_t N, int K, int d) {
   VqLayout L;
   L.grid = vq_grid(N, d);
   size_t o = 0;
   L.hdr = o; o += 256;
-  L.counts_fix = o; o += ((size_t)K * 4 + 255) / 256 * 256;       // [hdr, counts_fix] are zeroed every call
-  L.en = o; o += ((size_t)K * 4 + 255) / 256 * 256;
+  L.counts_fix = o; o += ((size_t)K * 4 + 255) / 256 * 256;       // [hdr, counts_fix / counts_acc] are zeroed every call
   L.partial = o; o += ((size_t)L.grid * 16 * 4 + 255) / 256 * 256;
   L.amb = o; o += ((size_t)N * 4 + 255) / 256 * 256;
   L.hist = o; o += ((size_t)L.grid * K * 4 + 255) / 256 * 256;
-  L.pack = o; o += (size_t)((K + 15) / 16 + 64) * 16 * 128 * 4;      // packed codebook, padded to a whole chunk, d_pad <= 128
+  L.prep = o; o += vq_prep_bytes_max(K);                           // prepared codebook of the one-call entry point
   L.total = o;
   return L;
 }
 
 template <typename T, int NF>
-static int launch_vq(const void* z, const float* E, int64_t N, int K, int d, int32_t* idx, void* zq, float* stats,
+static int launch_vq_prepare(const float* E, int64_t N, int K, int d, char* prep, hipStream_t st) {
+  typedef typename DT<T>::frag_t frag_t;
+  const VqPrep P = vq_prep_layout<T, NF>(N, K, d);
+  const int npack_blocks = (P.npk + 255) / 256;
+  FRL_LAUNCH((vq_prepare_kernel<T, NF>), dim3(npack_blocks + (P.kpad + 255) / 256), dim3(256), 0, st, E, K, d, (float*)(prep + P.en), P.kpad,
+             (frag_t*)(prep + P.pack), P.npk, npack_blocks);
+  return frl_check_launch("vq_prepare");
+}
+
+template <typename T, int NF>
+static int launch_vq(const void* z, const float* E, const char* prep, int64_t N, int K, int d, int32_t* idx, void* zq, float* stats,
                      int32_t* counts, char* ws, hipStream_t st) {
   typedef typename DT<T>::frag_t frag_t;
   const VqLayout L = vq_layout(N, K, d);
-  const int d_pad = NF * DT<T>::FE * 4;
+  const VqPrep P = vq_prep_layout<T, NF>(N, K, d);
   const int nw = vq_waves(N, d);
-  const int Kc = vq_chunk(K, d_pad, sizeof(T), nw);
+  const int Kc = P.Kc;
   VqHeader* hdr = (VqHeader*)(ws + L.hdr);
-  float* en = (float*)(ws + L.en);
-  FRL_HIP(hipMemsetAsync(ws, 0, L.en, st));                          // header + counts_fix
-  FRL_LAUNCH((vq_prep_kernel<T>), dim3((K + 255) / 256), dim3(256), 0, st, E, K, d, en, hdr);
-  const int kpadc = (K + Kc - 1) / Kc * Kc;                              // whole chunks (codes beyond K pack as zeros, masked by enl)
-  const int npk = (kpadc / 16) * NF * 64;
-  frag_t* pk = (frag_t*)(ws + L.pack);
-  FRL_LAUNCH((vq_pack_kernel<T, NF>), dim3((npk + 255) / 256), dim3(256), 0, st, E, K, d, pk, npk);
-  const size_t lds = (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc * 4 + (size_t)K * 4 + 128;
-  if (lds > 160 * 1024) return frl_fail(-3, "vq_assign: LDS budget exceeded (K too large for histogram)");
-  if (nw == 8) {
-    auto kern = vq_assign_kernel<T, NF, 2, 8>;
-    if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    FRL_LAUNCH(kern, dim3(L.grid), dim3(512), lds, st, (const T*)z, E, en, hdr, N, K, d, Kc, idx, (T*)zq,
-               (float*)(ws + L.partial), (int32_t*)(ws + L.hist), hdr, (int32_t*)(ws + L.amb), (const frag_t*)pk);
-  } else {
-    auto kern = vq_assign_kernel<T, NF, 4, 4>;
-    if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    FRL_LAUNCH(kern, dim3(L.grid), dim3(256), lds, st, (const T*)z, E, en, hdr, N, K, d, Kc, idx, (T*)zq,
-               (float*)(ws + L.partial), (int32_t*)(ws + L.hist), hdr, (int32_t*)(ws + L.amb), (const frag_t*)pk);
+  FRL_HIP(hipMemsetAsync(ws, 0, L.partial, st));                     // header + counts_fix (= counts_acc of the fused path)
+  if (prep == nullptr) {                                             // one-call entry point: prepare into the workspace first
+    const int rc = launch_vq_prepare<T, NF>(E, N, K, d, ws + L.prep, st);
+    if (rc) return rc;
+    prep = ws + L.prep;
   }
+  const float* en = (const float*)(prep + P.en);
+  const frag_t* pk = (const frag_t*)(prep + P.pack);
+  const bool fused = P.kpad == Kc;                                   // the whole codebook is one LDS chunk
+  size_t lds = (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc * 4 + (size_t)K * 4 + 128;
+  if (fused) lds += (size_t)Kc * 4 + (size_t)3 * VQ_AMB_CAP * 4 + 16;
+  if (lds > 160 * 1024) return frl_fail(-3, "vq_assign: LDS budget exceeded (K too large for histogram)");
+#define VQ_GO(NT_, NW_, FUSED_)                                                                                                    \
+  do {                                                                                                                             \
+    auto kern = vq_assign_kernel<T, NF, NT_, NW_, FUSED_>;                                                                         \
+    if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+    FRL_LAUNCH_AS("vq_assign_kernel", kern, dim3(L.grid), dim3(64 * NW_), lds, st, (const T*)z, E, en, hdr, N, K, d, Kc, idx, (T*)zq,     \
+                  (float*)(ws + L.partial), (int32_t*)(ws + L.hist), hdr, (int32_t*)(ws + L.amb), pk, (int32_t*)(ws + L.counts_fix), \
+                  counts, stats);                                                                                                  \
+  } while (0)
+  if (nw == 8) { if (fused) VQ_GO(2, 8, true); else VQ_GO(2, 8, false); }
+  else { if (fused) VQ_GO(4, 4, true); else VQ_GO(4, 4, false); }
+#undef VQ_GO
+  if (fused) return frl_check_launch("vq_assign");
   const size_t fix_lds = (size_t)4 * (d + 64 * (d + 1)) * sizeof(float);
   {
     auto fk = vq_fixup_kernel<T>;
@@ -845,7 +1090,7 @@ static int launch_vq(const void* z, const float* E, int64_t N, int K, int d, int
   if (res_lds <= 150 * 1024 && (d & 3) == 0) {
     auto fk = vq_fixup_lds_kernel<T>;
     if (res_lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds));
-    FRL_LAUNCH(fk, dim3(256), dim3(64 * VQ_FIXL_WAVES), res_lds, st, (const T*)z, E, K, d, (const int32_t*)(ws + L.amb), hdr, idx, (T*)zq,
+    FRL_LAUNCH_AS("vq_fixup_lds_kernel", fk, dim3(256), dim3(64 * VQ_FIXL_WAVES), res_lds, st, (const T*)z, E, K, d, (const int32_t*)(ws + L.amb), hdr, idx, (T*)zq,
                (int32_t*)(ws + L.counts_fix));
   } else {
     FRL_LAUNCH((vq_fixup_kernel<T>), dim3(VQ_FIX_WAVES / 4), dim3(256), fix_lds, st, (const T*)z, E, K, d,
@@ -899,29 +1144,54 @@ size_t frl_vq_workspace_bytes(int64_t N, int K, int d) {
   return L.total > bwd ? L.total : bwd;
 }
 
+// Dispatch on (dtype, d) to the fragment count NF of the kernels.
+#define VQ_DISPATCH(dtype, d, CALL)                                              \
+  do {                                                                          \
+    if ((dtype) == FRL_F32) {                                                   \
+      if ((d) <= 16) return CALL(float, 4);                                     \
+      if ((d) <= 32) return CALL(float, 8);                                     \
+      if ((d) <= 64) return CALL(float, 16);                                    \
+      return CALL(float, 32);                                                   \
+    } else if ((dtype) == FRL_BF16) {                                           \
+      if ((d) <= 32) return CALL(bf16, 1);                                      \
+      if ((d) <= 64) return CALL(bf16, 2);                                      \
+      return CALL(bf16, 4);                                                     \
+    }                                                                           \
+    return frl_fail(-2, "vq: bad dtype");                                       \
+  } while (0)
+
+// Prepared codebook: ||e||^2 + the packed MFMA fragment image of -2 e.  It depends on the codebook only, so a caller that keeps the
+// codebook fixed over several assignments (inference), or knows when it changes (once per optimizer step), builds it once with
+// frl_vq_prepare and hands it to frl_vq_assign_fwd_prepared: the assignment is then ONE kernel launch (plus a memset node).
+// N only selects the kernel variant (workgroup shape); pass the row count the assignments will use.
+size_t frl_vq_prepared_bytes(int K, int d) { return (K > 0 && d > 0 && d <= 128) ? vq_prep_bytes_max(K) : 0; }
+
+int frl_vq_prepare(const float* E, int64_t N, int K, int d, int dtype, void* prep, size_t prep_bytes, hipStream_t stream) {
+  if (N <= 0 || K <= 0 || d <= 0) return frl_fail(-2, "vq_prepare: empty input");
+  if (d > 128) return frl_fail(-2, "vq_prepare: d > 128 unsupported");
+  if (prep == nullptr || prep_bytes < frl_vq_prepared_bytes(K, d)) return frl_fail(-4, "vq_prepare: buffer too small");
+#define VQ_CALL_PREP(T_, NF_) launch_vq_prepare<T_, NF_>(E, N, K, d, (char*)prep, stream)
+  VQ_DISPATCH(dtype, d, VQ_CALL_PREP);
+#undef VQ_CALL_PREP
+}
+
 // z [N][d] (dtype), E [K][d] f32 master codebook.  Outputs: idx_out [N] int32, zq_out [N][d] (dtype, the
 // codebook rows rounded to dtype), stats_out [4] f32 = {sum ||z - z_q||^2, perplexity, #rows re-evaluated in
 // float64, 0}, counts_out [K] int32 code usage.  In bf16 mode distances are taken to the bf16-rounded codebook.
-int frl_vq_assign_fwd(const void* z, const float* E, int64_t N, int K, int d, int32_t* idx_out, void* zq_out,
-                      float* stats_out, int32_t* counts_out, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+// prep: NULL, or the image frl_vq_prepare wrote for THIS codebook content, dtype and row count class.
+int frl_vq_assign_fwd_prepared(const void* z, const float* E, const void* prep, int64_t N, int K, int d, int32_t* idx_out, void* zq_out,
+                               float* stats_out, int32_t* counts_out, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (N <= 0 || K <= 0 || d <= 0) return frl_fail(-2, "vq_assign: empty input");
   if (d > 128) return frl_fail(-2, "vq_assign: d > 128 unsupported");
   if (ws_bytes < frl_vq_workspace_bytes(N, K, d)) return frl_fail(-4, "vq_assign: workspace too small");
-  char* w = (char*)ws;
-  // partial_fix sits right after partial so that finalize sums one contiguous array
-  if (dtype == FRL_F32) {
-    if (d <= 16) return launch_vq<float, 4>(z, E, N, K, d, idx_out, zq_out, stats_out, counts_out, w, stream);
-    if (d <= 32) return launch_vq<float, 8>(z, E, N, K, d, idx_out, zq_out, stats_out, counts_out, w, stream);
-    if (d <= 64) return launch_vq<float, 16>(z, E, N, K, d, idx_out, zq_out, stats_out, counts_out, w, stream);
-    if (d <= 128) return launch_vq<float, 32>(z, E, N, K, d, idx_out, zq_out, stats_out, counts_out, w, stream);
-    return frl_fail(-2, "vq_assign: d > 128 unsupported in f32 mode");
-  } else if (dtype == FRL_BF16) {
-    if (d <= 32) return launch_vq<bf16, 1>(z, E, N, K, d, idx_out, zq_out, stats_out, counts_out, w, stream);
-    if (d <= 64) return launch_vq<bf16, 2>(z, E, N, K, d, idx_out, zq_out, stats_out, counts_out, w, stream);
-    if (d <= 128) return launch_vq<bf16, 4>(z, E, N, K, d, idx_out, zq_out, stats_out, counts_out, w, stream);
-    return launch_vq<bf16, 8>(z, E, N, K, d, idx_out, zq_out, stats_out, counts_out, w, stream);
-  }
-  return frl_fail(-2, "vq_assign: bad dtype");
+#define VQ_CALL_FWD(T_, NF_) launch_vq<T_, NF_>(z, E, (const char*)prep, N, K, d, idx_out, zq_out, stats_out, counts_out, (char*)ws, stream)
+  VQ_DISPATCH(dtype, d, VQ_CALL_FWD);
+#undef VQ_CALL_FWD
+}
+
+int frl_vq_assign_fwd(const void* z, const float* E, int64_t N, int K, int d, int32_t* idx_out, void* zq_out,
+                      float* stats_out, int32_t* counts_out, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+  return frl_vq_assign_fwd_prepared(z, E, nullptr, N, K, d, idx_out, zq_out, stats_out, counts_out, dtype, ws, ws_bytes, stream);
 }
 
 // g_z = g_out + gscale[0] * beta * 2/(N d) * (z - e_idx);  g_E[k] = gscale[1] * 2/(N d) * (n_k e_k - sum_{idx=k} z)
@@ -941,7 +1211,7 @@ int frl_vq_bwd(const void* g_out, const void* z, const void* zq, const float* E,
   if (dtype == FRL_F32) {
     auto kern = vq_bwd_kernel<float>;
     if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    FRL_LAUNCH(kern, dim3(VQ_BWD_WGS), dim3(256), lds, stream, (const float*)g_out, (const float*)z, E, idx, gscale,
+    FRL_LAUNCH_AS("vq_bwd_kernel", kern, dim3(VQ_BWD_WGS), dim3(256), lds, stream, (const float*)g_out, (const float*)z, E, idx, gscale,
                        cz, N, K, d, Kc, rows, (float*)g_z_out, slab);
     launch_slab_reduce<float, CodeEpi>((const float*)slab, VQ_BWD_WGS, (int64_t)K * d, CodeEpi{E, counts, gscale, ce, d, 0, g_E_out, sums_out}, stream);
   } else if (dtype == FRL_BF16) {

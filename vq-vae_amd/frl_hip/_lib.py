@@ -38,6 +38,9 @@ SIGNATURES = {
     "frl_conv_tap_bwd_weight": (c_int, [P, P, I, P, P, L, L, P, L, I, I, I, I, I, I, P, S, I, P]),
     "frl_vq_workspace_bytes": (S, [L, I, I]),
     "frl_vq_assign_fwd": (c_int, [P, P, L, I, I, P, P, P, P, I, P, S, P]),
+    "frl_vq_prepared_bytes": (S, [I, I]),
+    "frl_vq_prepare": (c_int, [P, L, I, I, I, P, S, P]),
+    "frl_vq_assign_fwd_prepared": (c_int, [P, P, P, L, I, I, P, P, P, P, I, P, S, P]),
     "frl_vq_bwd": (c_int, [P, P, P, P, P, P, P, F, L, I, I, P, P, P, I, P, S, P]),
     "frl_vq_ema_update": (c_int, [P, P, I, I, F, F, P, P, P, P, P]),
     "frl_vq_revive_dead_codes": (c_int, [P, P, L, P, L, I, I, ctypes.c_uint64, P, P, P, I, P]),
@@ -58,6 +61,10 @@ SIGNATURES = {
     "frl_mean_time_fwd": (c_int, [P, P, L, I, L, I, P]),
     "frl_add": (c_int, [P, P, F, P, L, I, P]),
     "frl_normalize_tiles": (c_int, [P, I, P, P, P, I, P, L, I, P]),
+    "frl_gather_locations_fwd": (c_int, [P, L, L, L, I, I, I, P, L, P, I, P]),
+    "frl_segment_sum_rows": (c_int, [P, P, P, L, I, P, L, I, P]),
+    "frl_infonce_fwd": (c_int, [P, I, P, P, P, L, P, L, F, I, P, P, P, P, P, P]),
+    "frl_infonce_pair_grads": (c_int, [P, I, P, P, P, P, L, L, F, I, P, P, P]),
     "frl_mutual_knn_max_points": (S, [I]),
     "frl_mutual_knn": (c_int, [P, I, I, P, P, F, I, P, P, P]),
     "frl_host_parallel_copy": (c_int, [P, P, S, I]),
@@ -77,7 +84,7 @@ SIGNATURES = {
     "frl_tcn_block_bwd_fused_workspace_bytes": (S, [L]),
     "frl_tcn_block_bwd_fused": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, F, P, S, P]),
     "frl_adamw_workspace_bytes": (S, []),
-    "frl_adamw_clip_step": (c_int, [P, I, P, P, I, F, F, D, D, F, I, P, P, P, P, S, P]),
+    "frl_adamw_clip_step": (c_int, [P, I, P, P, I, F, F, D, D, F, I, P, P, P, P, P, S, P]),
     "frl_multi_tensor_scale_copy": (c_int, [P, I, P, P, I, F, P]),
     "frl_tcn_hot_supported": (c_int, [I, I, I, I, I, I, I]),
     "frl_tcn_hot_fwd_workspace_bytes": (S, []),

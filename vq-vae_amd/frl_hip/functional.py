@@ -203,8 +203,8 @@ class VQFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, z, codebook):
-        idx, zq, stats, counts = ops.vq_assign(z, codebook)
+    def forward(ctx, z, codebook, prep=None):
+        idx, zq, stats, counts = ops.vq_assign(z, codebook, prep)
         d = z.shape[-1]
         n = z.numel() // d
         ctx.set_materialize_grads(False)
@@ -224,7 +224,7 @@ class VQFn(Function):
             gs[1] = g_cb
         gz, ge, _ = ops.vq_bwd(_c(g_zq), z, codebook, idx, counts, gs, 1.0,
                                want_gz=ctx.needs_input_grad[0], want_ge=ctx.needs_input_grad[1], zq=zq)
-        return gz, ge
+        return gz, ge, None
 
 
 class MseFn(Function):

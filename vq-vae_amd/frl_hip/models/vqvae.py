@@ -48,10 +48,22 @@ class VectorQuantizer(nn.Module):
         # apply_ema(ok) -- after the loss is known -- instead of being folded into the running averages inside forward().
         self.defer_ema = False
         self._pending_ema = None
+        self._prepared = None                               # (key, image): see prepared()
+
+    def prepared(self, dtype: torch.dtype, n_rows: int) -> torch.Tensor:
+        """Prepared image of the codebook for rows of `dtype` (norms + packed fragments, `ops.vq_prepare`), rebuilt only when the
+        codebook has changed: keyed on the parameter's storage and version counter (HipAdamW, the EMA update and the dead-code
+        revival bump it; so does every in-place torch operation)."""
+        cb = self.codebook
+        key = (cb.data_ptr(), cb._version, dtype)
+        if self._prepared is None or self._prepared[0] != key:
+            buf = self._prepared[1] if self._prepared is not None else None
+            self._prepared = (key, ops.vq_prepare(cb.detach(), n_rows, dtype, out=buf))
+        return self._prepared[1]
 
     def forward(self, z_rows: torch.Tensor):
         """z_rows [N, d] -> (z_q [N,d] with straight-through gradient, vq_loss, perplexity, idx int32 [N])."""
-        zq, l_cb, l_cm, perp, idx, counts = Fh.VQFn.apply(z_rows, self.codebook)
+        zq, l_cb, l_cm, perp, idx, counts = Fh.VQFn.apply(z_rows, self.codebook, self.prepared(z_rows.dtype, z_rows.shape[0]))
         self.last_counts = counts
         if self.quantizer == "ema":
             vq_loss = self.beta * l_cm
@@ -81,7 +93,10 @@ class VectorQuantizer(nn.Module):
             dist.all_reduce(sums)
             dist.all_reduce(counts)
         ops.vq_ema_update(sums, counts, self.ema_count, self.ema_sum, self.codebook.data, self.ema_decay, self.ema_eps, ok)
-        torch.autograd.graph.increment_version(self.codebook)
+        if self._prepared is not None:                                     # the cached fragment image belongs to the old codebook
+            self._prepared = ((None, None, self._prepared[0][2]), self._prepared[1])   # (buffer kept: captured graphs hold its address)
+        if self.defer_ema:                                                 # (inside forward() the autograd graph still holds the codebook)
+            torch.autograd.graph.increment_version(self.codebook)
 
     def drop_ema(self) -> None:
         self._pending_ema = None

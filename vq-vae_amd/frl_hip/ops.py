@@ -179,9 +179,24 @@ conv1x1_bwd_weight = _timed("conv1x1_bwd_weight")(_conv1x1_bwd_weight_impl)
 # ----------------------------------------------------------------------------------------------
 # vector quantizer (csrc/vq.hip)
 # ----------------------------------------------------------------------------------------------
+@_timed("vq_prepare")
+def vq_prepare(codebook: torch.Tensor, n_rows: int, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Prepared image of the codebook (norms + packed MFMA fragments) for `vq_assign(..., prep=)`; valid until the codebook changes."""
+    k, d = codebook.shape
+    cb = _f32(codebook, "codebook")
+    lib = _lib.load()
+    nbytes = lib.frl_vq_prepared_bytes(k, d)
+    if out is None or out.numel() < nbytes or out.device != cb.device:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=cb.device)
+    check(lib.frl_vq_prepare(_p(cb), int(n_rows), k, d, BF16 if dtype == torch.bfloat16 else F32, _p(out), out.numel(), _stream()),
+          "frl_vq_prepare")
+    return out
+
+
 @_timed("vq_assign")
-def vq_assign(z: torch.Tensor, codebook: torch.Tensor):
-    """z [N,d] rows, codebook [K,d] f32 -> (idx int32 [N], z_q [N,d], stats f32 [4], counts int32 [K])."""
+def vq_assign(z: torch.Tensor, codebook: torch.Tensor, prep: Optional[torch.Tensor] = None):
+    """z [N,d] rows, codebook [K,d] f32 -> (idx int32 [N], z_q [N,d], stats f32 [4], counts int32 [K]).
+    prep: image from `vq_prepare` for this codebook content and z.dtype (None: built inside the call)."""
     k, d = codebook.shape
     _chk_rows(z, d, "vq_assign.z")
     cb = _f32(codebook, "codebook")
@@ -192,8 +207,10 @@ def vq_assign(z: torch.Tensor, codebook: torch.Tensor):
     zq = torch.empty_like(z)
     stats = torch.empty(4, dtype=torch.float32, device=z.device)
     counts = torch.empty(k, dtype=torch.int32, device=z.device)
-    check(lib.frl_vq_assign_fwd(_p(z), _p(cb), n, k, d, _p(idx), _p(zq), _p(stats), _p(counts), _dt(z), _p(ws),
-                                ws.numel(), _stream()), "frl_vq_assign_fwd")
+    if prep is not None and (prep.dtype != torch.uint8 or prep.device != z.device or prep.numel() < lib.frl_vq_prepared_bytes(k, d)):
+        raise ValueError("vq_assign: prep is not a prepared-codebook image for this codebook")
+    check(lib.frl_vq_assign_fwd_prepared(_p(z), _p(cb), _p(prep), n, k, d, _p(idx), _p(zq), _p(stats), _p(counts), _dt(z), _p(ws),
+                                         ws.numel(), _stream()), "frl_vq_assign_fwd")
     return idx, zq, stats, counts
 
 
@@ -667,3 +684,61 @@ def decoder_mse_bwd(z, w1, b1, w2, b2, target, mask, gscale, stats):
     check(lib.frl_decoder_mse_bwd(_p(z), _p(w1), _p(b1), _p(w2), _p(b2), _p(target), _p(mask), _p(gscale), _p(stats), _p(dz), _p(dw1),
                                   _p(db1), _p(dw2), _p(db2), p, cz, _p(ws), ws.numel(), _stream()), "frl_decoder_mse_bwd")
     return dz, dw1, db1, dw2, db2
+
+
+# ----------------------------------------------------------------------------------------------
+# sparse-location gather + InfoNCE over mined pairs (csrc/contrastive.hip)
+# ----------------------------------------------------------------------------------------------
+@_timed("gather_locations")
+def gather_locations(feature: torch.Tensor, coords: torch.Tensor) -> torch.Tensor:
+    """feature [C, H, W] with any strides (float32 | bfloat16), coords int64 [N, 2] (row, col) -> [N, C] contiguous."""
+    if not feature.is_cuda:
+        raise _lib.FrlHipError("gather_locations: tensor must live on the GPU (no CPU fallback)")
+    c, h, w = feature.shape
+    if coords.dtype != torch.int64 or not coords.is_contiguous() or coords.device != feature.device:
+        raise ValueError("gather_locations: coords must be a contiguous int64 [N, 2] tensor on the feature's device")
+    n = coords.shape[0]
+    out = torch.empty(n, c, dtype=feature.dtype, device=feature.device)
+    sc, sh, sw = feature.stride()
+    check(_lib.load().frl_gather_locations_fwd(_p(feature), sc, sh, sw, c, h, w, _p(coords), n, _p(out), _dt(feature), _stream()),
+          "frl_gather_locations_fwd")
+    return out
+
+
+@_timed("segment_sum_rows")
+def segment_sum_rows(vals: torch.Tensor, order: Optional[torch.Tensor], keys_sorted: torch.Tensor, out: torch.Tensor, accumulate: bool = False):
+    """out[key] (+)= sum of vals[order[i]] over each run of equal keys_sorted[i]; rows are summed in list order (reproducible)."""
+    m, d = vals.shape
+    if vals.dtype != torch.float32 or not vals.is_contiguous() or out.dtype != torch.float32 or not out.is_contiguous() or out.shape[-1] != d:
+        raise ValueError("segment_sum_rows: vals [M, D] and out [.., D] must be contiguous float32")
+    for t in (order, keys_sorted):
+        if t is not None and (t.dtype != torch.int64 or not t.is_contiguous() or t.numel() != m):
+            raise ValueError("segment_sum_rows: order / keys must be contiguous int64 [M]")
+    check(_lib.load().frl_segment_sum_rows(_p(vals), _p(order), _p(keys_sorted), m, d, _p(out), d, int(accumulate), _stream()),
+          "frl_segment_sum_rows")
+    return out
+
+
+@_timed("infonce_fwd")
+def infonce_fwd(emb, pairs, weights, is_pos, seg, temperature: float, sim: int, want_coef: bool = True):
+    """Pairs sorted by anchor with segment bounds `seg` -> (loss f32 [1], sims [T], coef [T] or None)."""
+    t, d = pairs.shape[0], emb.shape[1]
+    sims = torch.empty(t, dtype=torch.float32, device=emb.device)
+    logits = torch.empty_like(sims)
+    nseg = seg.numel() - 1
+    loss_a = torch.empty(nseg, dtype=torch.float32, device=emb.device)
+    coef = torch.empty_like(sims) if want_coef else None
+    loss = torch.empty(1, dtype=torch.float32, device=emb.device)
+    check(_lib.load().frl_infonce_fwd(_p(emb), d, _p(pairs), _p(weights), _p(is_pos), t, _p(seg), nseg, float(temperature), int(sim),
+                                      _p(sims), _p(logits), _p(loss_a), _p(coef), _p(loss), _stream()), "frl_infonce_fwd")
+    return loss, sims, coef
+
+
+@_timed("infonce_bwd")
+def infonce_pair_grads(emb, pairs, sims, coef, gscale, nseg: int, temperature: float, sim: int):
+    t, d = pairs.shape[0], emb.shape[1]
+    ga = torch.empty(t, d, dtype=torch.float32, device=emb.device)
+    gb = torch.empty_like(ga)
+    check(_lib.load().frl_infonce_pair_grads(_p(emb), d, _p(pairs), _p(sims), _p(coef), _p(gscale), t, nseg, float(temperature), int(sim),
+                                             _p(ga), _p(gb), _stream()), "frl_infonce_pair_grads")
+    return ga, gb

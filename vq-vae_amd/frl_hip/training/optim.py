@@ -59,6 +59,7 @@ class HipAdamW:
         self._live = None
         self._keep = None
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.lr_dev: Optional[torch.Tensor] = None         # device float[1]: when set, the kernels read the learning rate from it
         self.counters = torch.zeros(2, dtype=torch.int32, device=self.device)   # {updates applied, updates skipped}, device-side
 
     def zero_grad(self, set_to_none: bool = True):
@@ -109,7 +110,9 @@ class HipAdamW:
                                       float(b1), float(b2),
                                       float(self.param_groups[0]["eps"]), self.step_count, ctypes.c_void_p(self.grad_norm.data_ptr()),
                                       ctypes.c_void_p(ok.data_ptr()) if ok is not None else None, ctypes.c_void_p(self.counters.data_ptr()),
+                                      ctypes.c_void_p(self.lr_dev.data_ptr()) if self.lr_dev is not None else None,
                                       ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "frl_adamw_clip_step")
+        torch.autograd.graph.increment_version(self.params)     # the kernel wrote through raw pointers: tell torch (version-keyed caches)
         return self.grad_norm
 
     @property

@@ -56,6 +56,13 @@ class VQVAETrainer:
         if self.reducer is not None and on_gpu and getattr(model, "concurrent_phase", False) and hasattr(model, "phase_stream"):
             self.reducer.extra_streams.append(model.phase_stream(rest[0].device))
 
+    def opt_lr_dev_sync(self) -> bool:
+        """Eager steps after a graph was captured: the optimizer reads the learning rate from its device word, keep it current."""
+        if self.hip_opt and self.opt.lr_dev is not None:
+            self.opt.lr_dev.fill_(float(self.opt.param_groups[0]["lr"]))
+            return True
+        return False
+
     @property
     def n_skipped(self) -> int:
         """Batches skipped by the isfinite guard (reads the device counter when the HIP optimizer is in use)."""
@@ -73,10 +80,160 @@ class VQVAETrainer:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         return bool(ok.item() > 0)
 
+    # ------------------------------------------------------------------------------------------------------------------
+    # The whole step as ONE hipGraph launch.  A step is ~190 kernel launches through ctypes plus ~400 small ATen calls; at 256 tiles
+    # the host needs about as long to queue them as the GPU needs to run them, so every kernel that gets faster moves the step from
+    # GPU-bound to host-bound.  Captured once (forward on both streams, autograd backward, gradient clip + AdamW, codebook hooks,
+    # fragment-image refresh), a step costs the host one copy into the static input, one word for the learning rate and one replay.
+    # Everything the step decides per batch already lives on the device (isfinite flag, update counters); the learning rate moves
+    # there too (HipAdamW.lr_dev).  Host-side values that are baked into the capture (beta, lambda_recon / lambda_vq) re-capture
+    # when they change; a lambda_vq(step) schedule that changes every step keeps the eager path.
+    # ------------------------------------------------------------------------------------------------------------------
+    def graph_supported(self) -> bool:
+        return bool(self.hip_opt and self.check_finite and self.lambda_vq_schedule is None and self.reducer is None)
+
+    def _graph_key(self, tile, mask):
+        q = getattr(self.model, "quant", None)
+        return (tuple(tile.shape), tile.dtype, None if mask is None else (tuple(mask.shape), mask.dtype),
+                getattr(q, "beta", None), getattr(self.model, "lambda_vq", None), getattr(self.model, "lambda_recon", None),
+                getattr(self.model, "concurrent_phase", None), self.max_norm)
+
+    def step_graphed(self, tile: torch.Tensor, mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """Same step as `step`, replayed from a captured hipGraph (falls back to `step` when graph_supported() is False).
+        The returned tensors are the graph's static outputs: they are overwritten by the next call."""
+        if not self.graph_supported():
+            return self.step(tile, mask)
+        # A graph reads its input at a fixed address.  Inputs that come from a small ring of device buffers (TilePrefetcher slots,
+        # the benchmark's tile pool) get one graph per buffer -- all of them share one memory pool, they never run concurrently --
+        # so that no copy into a staging tensor is needed; beyond MAX_GRAPHS distinct buffers the input is copied into the first one.
+        key = self._graph_key(tile, mask)
+        graphs = self.__dict__.setdefault("_graphs", {})
+        if graphs and next(iter(graphs.values()))["key"] != key:
+            graphs.clear()                                          # shapes / baked scalars changed: start over
+            self._graph_pool = None
+        slot = (tile.data_ptr(), None if mask is None else mask.data_ptr())
+        g = graphs.get(slot)
+        if g is None:
+            if len(graphs) < self.MAX_GRAPHS:
+                g = graphs[slot] = self._capture(tile, mask, key)
+            else:
+                g = next(iter(graphs.values()))
+        lr_now = cosine_lr(self.step_idx, self.total_steps, self.lr, self.min_lr)
+        g["lr_host"].fill_(lr_now)
+        self.opt.lr_dev.copy_(g["lr_host"], non_blocking=True)     # pinned word -> device word, on the stream of the replay
+        if g["tile"].data_ptr() != tile.data_ptr():
+            g["tile"].copy_(tile, non_blocking=True)
+        if mask is not None and g["mask"].data_ptr() != mask.data_ptr():
+            g["mask"].copy_(mask, non_blocking=True)
+        g["graph"].replay()
+        mgr = getattr(self.model, "codebook_manager", None)
+        if mgr is not None and hasattr(mgr, "after_step"):         # host-scheduled (every reset_every steps): stays outside the graph
+            if mgr.after_step(self.model.quant, self.opt):
+                for qz in self.model._quantizers():
+                    if qz._prepared is not None:
+                        qz.prepared(qz._prepared[0][2], 1 << 20)
+        self.step_idx += 1
+        out = g["out"]
+        out["lr"] = lr_now
+        return out
+
+    MAX_GRAPHS = 8
+
+    def _capture(self, tile, mask, key):
+        dev = tile.device
+        static_tile, static_mask = tile, mask                      # the caller's buffers ARE the static inputs (kept alive by the graph record)
+        if self.opt.lr_dev is None:
+            self.opt.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        lr_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+        lr_host.fill_(cosine_lr(self.step_idx, self.total_steps, self.lr, self.min_lr))
+        self.opt.lr_dev.copy_(lr_host)
+        mgr = getattr(self.model, "codebook_manager", None)
+        saved_after = None
+        if mgr is not None and hasattr(mgr, "after_step"):         # the revival pass is scheduled by the host: not part of the body
+            saved_after, mgr.after_step = mgr.after_step, (lambda *a, **k: False)
+        try:
+            # Warm-up on a side stream (allocator pools, workspaces, lazily built tables), with the state restored afterwards: the
+            # capture must not consume optimizer steps.  Three eager steps move parameters, moments and counters -- snapshot them.
+            snap = self._snapshot()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._step_body(static_tile, static_mask)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, pool=getattr(self, "_graph_pool", None)):
+                out = self._step_body(static_tile, static_mask)
+            if getattr(self, "_graph_pool", None) is None:
+                self._graph_pool = graph.pool()
+            self._restore(snap)
+        finally:
+            if saved_after is not None:
+                mgr.after_step = saved_after
+        return dict(key=key, graph=graph, tile=static_tile, mask=static_mask, out=out, lr_host=lr_host)
+
+    def _snapshot(self):
+        m, o = self.model, self.opt
+        st = dict(params=[p.detach().clone() for p in o.params], m=[t.clone() for t in o.exp_avg], v=[t.clone() for t in o.exp_avg_sq],
+                  counters=o.counters.clone(), step_count=o.step_count, lag=list(o.lag),
+                  buffers=[b.detach().clone() for b in m.buffers()])
+        mgr = getattr(m, "codebook_manager", None)
+        if mgr is not None and getattr(mgr, "window", None) is not None:
+            st["window"] = mgr.window.clone()
+        return st
+
+    def _restore(self, st):
+        m, o = self.model, self.opt
+        with torch.no_grad():
+            for p, q in zip(o.params, st["params"]):
+                p.copy_(q)
+            for a, b in zip(o.exp_avg, st["m"]):
+                a.copy_(b)
+            for a, b in zip(o.exp_avg_sq, st["v"]):
+                a.copy_(b)
+            o.counters.copy_(st["counters"])
+            for b, q in zip(m.buffers(), st["buffers"]):
+                b.copy_(q)
+        o.step_count, o.lag = st["step_count"], list(st["lag"])
+        o._key = None
+        mgr = getattr(m, "codebook_manager", None)
+        if mgr is not None and "window" in st:
+            mgr.window.copy_(st["window"])
+        if hasattr(m, "_quantizers"):
+            for qz in m._quantizers():
+                qz.drop_ema()
+                if qz._prepared is not None:
+                    # state that crosses steps must keep ONE address for every graph: the image written behind the optimizer of step n
+                    # (by whichever graph ran it) is read by the forward of step n + 1 (possibly another graph).  Keep the buffer,
+                    # rebuild its content for the restored codebook.
+                    dtype = qz._prepared[0][2]
+                    qz._prepared = ((None, None, dtype), qz._prepared[1])
+                    qz.prepared(dtype, 1 << 20)
+
+    def _step_body(self, tile, mask):
+        """forward -> device isfinite flag -> backward -> clip + AdamW -> codebook hooks -> fragment-image refresh (no host-side
+        schedule, no host sync): the part of `step` that a graph can hold."""
+        self.model.train()
+        self.opt.zero_grad(set_to_none=True)
+        out = self.model.forward_tiles(tile, mask)
+        loss = out["loss"]
+        ok = (loss.detach().float() * 0.0 == 0.0).float().reshape(1)
+        loss.backward()
+        out["grad_norm"] = self.opt.step(self.max_norm, None, ok)
+        if getattr(self.model, "defer_codebook_hooks", False):
+            self.model.commit_codebook_hooks(ok)
+        if hasattr(self.model, "_quantizers"):
+            for qz in self.model._quantizers():
+                if qz._prepared is not None:
+                    qz.prepared(qz._prepared[0][2], 1 << 20)
+        return out
+
     def step(self, tile: torch.Tensor, mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         lr_now = cosine_lr(self.step_idx, self.total_steps, self.lr, self.min_lr)
         for g in self.opt.param_groups:
             g["lr"] = lr_now
+        if self.opt_lr_dev_sync():
+            pass
         if self.lambda_vq_schedule is not None:                # loss = lambda_recon L + lambda_vq(step) (L_codebook + beta L_commit)
             self.model.lambda_vq = self.lambda_vq_schedule(self.step_idx)
         self.model.train()
@@ -124,6 +281,12 @@ class VQVAETrainer:
         mgr = getattr(self.model, "codebook_manager", None)
         if mgr is not None and hasattr(mgr, "after_step"):                   # dead-code revival every `reset_every` steps, on the device
             mgr.after_step(self.model.quant, self.opt)
+        if self.hip_opt and hasattr(self.model, "_quantizers"):
+            # rebuild the codebooks' fragment images right behind the update (optimizer, EMA, revival have all run): the next
+            # step's assignment is then a single kernel launch
+            for qz in self.model._quantizers():
+                if qz._prepared is not None:
+                    qz.prepared(qz._prepared[0][2], 1 << 20)
         self.step_idx += 1
         out["lr"] = lr_now
         return out
