@@ -38,6 +38,22 @@ int frl_device_arch(char* buf, int n); /* must report gfx950 */
 int frl_kernel_timing_enable(int on);
 int frl_kernel_timing_report(char* buf, int n);
 
+/* ---- weight-image cache ------------------------------------------------------------------------------------------------------
+ * Every conv-like call first rewrites its float32 weights into a packed MFMA fragment image (a small prologue launch per call).  A
+ * caller that knows when the weights change (the trainer: once per optimizer step) keeps the images in an arena of its own:
+ *   h = frl_pack_cache_create(arena, bytes)   arena: device memory owned by the caller, at least frl_pack_cache_table_bytes() + images
+ *   frl_pack_cache_activate(h)                calls made from now on (any thread) find / register their image in cache h and skip the
+ *                                             prologue on a hit; frl_pack_cache_activate(0) restores the default (pack per call)
+ *   frl_pack_cache_refresh(h, stream)         rewrites EVERY registered image from the current weights with ONE launch
+ *   frl_pack_cache_destroy(h)
+ * An image is valid from its registration (or the last refresh) until its weights change: refresh right after the optimizer. */
+size_t frl_pack_cache_table_bytes(void);
+int frl_pack_cache_create(void* arena, size_t bytes);
+int frl_pack_cache_destroy(int handle);
+int frl_pack_cache_activate(int handle);      /* returns the previously active handle */
+int frl_pack_cache_images(int handle);        /* number of registered images */
+int frl_pack_cache_refresh(int handle, frl_stream_t stream);
+
 /* ---- pointwise (1x1) convolution --------------------------------------------------------------------------------
  * nn.Conv2d(.,.,1): frl/models/conv2d_encoder.py:106-114; spatial.py:262-263; representation.py:169;
  * conditioning.py:55-67; decoder template heads.py:128-198.  w [Cout][Cin], bias [Cout] or NULL. */

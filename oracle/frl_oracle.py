@@ -590,3 +590,47 @@ def mutual_knn_pairs_np(features: np.ndarray, coord_list: list, offsets: list, k
         knn[i, :kk] = order
     pairs = [(i, int(j)) for i in range(n) for j in knn[i] if j >= 0 and (knn[j] == i).any()]     # pairs.py:596-610
     return np.asarray(pairs, dtype=np.int64).reshape(-1, 2), knn
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# InfoNCE over mined pairs + location gather (frl/losses/contrastive.py:29-212, frl/utils/spatial.py:132-173)
+# ---------------------------------------------------------------------------------------------------------------------------
+def contrastive_loss_oracle(embeddings: torch.Tensor, pos_pairs: torch.Tensor, neg_pairs: torch.Tensor, pos_weights=None,
+                            neg_weights=None, temperature: float = 0.07, similarity: str = "l2") -> torch.Tensor:
+    """Anchor by anchor in plain loops (float64 when the embeddings are): for every anchor a with at least one positive
+
+        L_a = -log(sum_p w_p exp(l_p - m) + 1e-8) + log(sum_{p,n} w exp(l - m) + 1e-8),   l = sim / t,  m = max logit of the anchor
+
+    which is what the reference's scatter_reduce('amax') / scatter_add formulation evaluates (contrastive.py:171-209); loss = mean
+    over those anchors; negatives of anchors without a positive are ignored (:160-170); empty pos_pairs -> 0 (:104-105)."""
+    if pos_pairs.numel() == 0:
+        return torch.zeros((), dtype=embeddings.dtype)
+    dim = embeddings.shape[1]
+
+    def sim(a, b):
+        if similarity == "l2":
+            return -((a - b) ** 2).sum() / dim
+        if similarity == "dot":
+            return (a * b).sum()
+        if similarity == "cosine":
+            return (a / a.norm().clamp_min(1e-12) * (b / b.norm().clamp_min(1e-12))).sum()
+        raise ValueError(f"Unknown similarity function: {similarity}")
+
+    pw = torch.ones(pos_pairs.shape[0], dtype=embeddings.dtype) if pos_weights is None else pos_weights.to(embeddings.dtype)
+    nw = torch.ones(neg_pairs.shape[0], dtype=embeddings.dtype) if neg_weights is None else neg_weights.to(embeddings.dtype)
+    losses = []
+    for a in sorted(set(pos_pairs[:, 0].tolist())):
+        pos = [torch.log(pw[i]) + sim(embeddings[a], embeddings[int(pos_pairs[i, 1])]) / temperature
+               for i in range(pos_pairs.shape[0]) if int(pos_pairs[i, 0]) == a]
+        neg = [torch.log(nw[i]) + sim(embeddings[a], embeddings[int(neg_pairs[i, 1])]) / temperature
+               for i in range(neg_pairs.shape[0]) if int(neg_pairs[i, 0]) == a]
+        pos_t, all_t = torch.stack(pos), torch.stack(pos + neg)
+        m = all_t.max()     # NOT detached: the reference's scatter_reduce_('amax') is differentiable, and with eps inside the logarithms
+        #                     the +-m terms do not cancel exactly (an O(1e-8) term on the anchor's arg-max logit)
+        losses.append(-torch.log(torch.exp(pos_t - m).sum() + 1e-8) + torch.log(torch.exp(all_t - m).sum() + 1e-8))
+    return torch.stack(losses).mean()
+
+
+def extract_at_locations_np(feature: np.ndarray, coords: np.ndarray) -> np.ndarray:
+    """feature [C, H, W], coords [N, 2] (row, col) -> [N, C]  (frl/utils/spatial.py:132-154)."""
+    return np.stack([feature[:, int(r), int(c)] for r, c in coords], axis=0) if len(coords) else np.zeros((0, feature.shape[0]), feature.dtype)

@@ -189,3 +189,23 @@ def test_oracle_mutual_knn_equals_reference_output(golden_dir, case):
     assert np.array_equal(pairs, fx["pairs"])
     have = set(map(tuple, pairs.tolist()))
     assert all((j, i) in have for i, j in have)                           # both directions of every mutual pair
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+def test_oracle_contrastive_loss_equals_reference_output(golden_dir, case):
+    """tests/golden/contrastive_*.npz: loss and gradient of the reference's contrastive_loss in float64 (oracle/make_contrastive_golden.py)."""
+    import frl_oracle as O
+    fx = np.load(os.path.join(golden_dir, f"contrastive_{case}.npz"))
+    emb = torch.from_numpy(fx["emb"]).requires_grad_(True)
+    pw = torch.from_numpy(fx["pw"]) if "pw" in fx.files else None
+    nw = torch.from_numpy(fx["nw"]) if "nw" in fx.files else None
+    loss = O.contrastive_loss_oracle(emb, torch.from_numpy(fx["pos"]), torch.from_numpy(fx["neg"]), pw, nw, float(fx["t"]), str(fx["sim"]))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(fx["loss64"])) < 1e-12 * max(1.0, abs(float(fx["loss64"])))
+    assert np.abs(emb.grad.numpy() - fx["grad64"]).max() < 1e-12 * max(1.0, np.abs(fx["grad64"]).max())
+
+
+def test_oracle_extract_at_locations(golden_dir):
+    import frl_oracle as O
+    fx = np.load(os.path.join(golden_dir, "extract_locations.npz"))
+    assert np.array_equal(O.extract_at_locations_np(fx["feat"], fx["coords"]), fx["out"])

@@ -320,6 +320,47 @@ def test_graph_captured_step_reproduces_the_eager_trajectory(golden_dir):
     assert int(m0.codebook_manager.revived.item()) == int(m1.codebook_manager.revived.item())
 
 
+def test_weight_image_cache_changes_nothing_but_the_launch_count():
+    """VQVAETrainer(pack_cache=True): the packed MFMA fragment images of all conv weights are kept in the trainer's arena and rewritten
+    by one launch behind the optimizer.  The generic repack kernel must reproduce the per-call pack kernels bit for bit: three steps
+    with and without the cache end in EQUAL parameters (bf16 hot kernels: pointwise, 3x3, fused TCN and decoder images), and a weight
+    edited behind the trainer's back (load_state_dict) is picked up before the next step."""
+    from frl_hip.models import VQVAE
+    from frl_hip.training.trainer import VQVAETrainer
+
+    def make():
+        torch.manual_seed(0)
+        m = VQVAE(in_features=64, codebook_size=64, emb_dim=64, beta=0.25, type_encoder_dropout=0.0, phase_tcn_dropout=0.0,
+                  compute_dtype=torch.bfloat16).to(DEV)
+        with torch.no_grad():
+            m.quant.codebook.copy_(torch.randn(64, 64, generator=torch.Generator().manual_seed(7)))
+        return m
+
+    g = torch.Generator().manual_seed(11)
+    tiles = [torch.randn(2, 5, 32, 32, 64, generator=g).to(torch.bfloat16).to(DEV) for _ in range(3)]
+    runs = []
+    for cached in (False, True):
+        m = make()
+        tr = VQVAETrainer(m, lr=1e-3, total_steps=10, pack_cache=cached)
+        losses = [float(tr.step(t)["loss"].detach()) for t in tiles]
+        if cached:
+            assert tr.pack_cache is not None and tr.pack_cache.images >= 20
+            n_img = tr.pack_cache.images
+        else:
+            assert tr.pack_cache is None
+        # edit a weight behind the trainer's back, then one more step: both must see the new value
+        with torch.no_grad():
+            m.encoder.layers[0].weight.mul_(0.5)
+        losses.append(float(tr.step(tiles[0])["loss"].detach()))
+        if cached:
+            assert tr.pack_cache.images == n_img                       # nothing new to register after the first step
+        runs.append((m, losses))
+    (m0, l0), (m1, l1) = runs
+    assert l0 == l1
+    for (n, p), (_, q) in zip(m0.named_parameters(), m1.named_parameters()):
+        assert torch.equal(p, q), n
+
+
 def test_configs1_train_step_end_to_end():
     """BASELINE configs[1] as bench.py measures it (256 tiles of 5x32x32x64, K = 512, d = 64, bf16): one full train step through the
     HIP path -- VQ indices are the exact float64 argmin of the latents the encoder produced, every loss term is finite, parameters move."""

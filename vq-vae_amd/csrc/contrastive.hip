@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void pair_logits_kernel(const float* __restric
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // per anchor segment [seg[a], seg[a+1]) of the anchor-sorted pair list (is_pos marks the positives): one wave per segment.
-// loss_a = -log(pos_sum + eps) + log(all_sum + eps)  with sums of exp(logit - max); coef[i] = d loss_a / d logit_i.
+// loss_a = -log(pos_sum + eps) + log(all_sum + eps)  with sums of exp(logit - max); coef[i] = d loss_a / d logit_i (max included).
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void infonce_segments_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ is_pos,
                                                                const int64_t* __restrict__ seg, int64_t nseg, float* __restrict__ loss_a,
@@ -117,10 +117,18 @@ __global__ __launch_bounds__(256) void infonce_segments_kernel(const float* __re
     const float eps = 1e-8f;
     if (lane == 0) loss_a[a] = -logf(sp + eps) + logf(sa + eps);
     if (coef != nullptr) {
+      // d loss_a / d logit_i through the exponentials, plus the path through the maximum itself: the reference's amax is differentiable
+      // and with eps inside the logarithms the +-m terms leave  sp / (sp + eps) - sa / (sa + eps)  on the arg-max logit(s) (shared
+      // evenly between tied maxima, as torch's amax backward does) -- 1e-3 of the gradient when the positives sit far below the maximum
       const float ia = 1.f / (sa + eps), ip = 1.f / (sp + eps);
+      int nmax = 0;
+      for (int64_t i = lo + lane; i < hi; i += 64) nmax += logits[i] == m ? 1 : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) nmax += __shfl_xor(nmax, o, 64);
+      const float gmax = eps * (ia - ip) / (float)(nmax > 0 ? nmax : 1);      // = sp/(sp+eps) - sa/(sa+eps) without the cancellation
       for (int64_t i = lo + lane; i < hi; i += 64) {
         const float e = expf(logits[i] - m);
-        coef[i] = e * ia - (is_pos[i] ? e * ip : 0.f);
+        coef[i] = e * ia - (is_pos[i] ? e * ip : 0.f) + (logits[i] == m ? gmax : 0.f);
       }
     }
   }

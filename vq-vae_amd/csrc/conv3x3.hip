@@ -11,6 +11,7 @@
 // Roofline: MFMA (147 456 FLOP/px at 128->64 vs 384 B/px bf16 = 384 FLOP/B, above the 312 FLOP/B balance point).
 #include "frl_common.hpp"
 #include "frl_host.hpp"
+#include "frl_pack.hpp"
 #include <type_traits>
 #include "frl_reduce.hpp"
 
@@ -513,7 +514,13 @@ static int launch_c3(const void* x, const void* xm, int mask_act, const float* w
   const int MBt = (Cout + 15) / 16;
   const size_t nfrag = (size_t)((MBt + 3) / 4) * ((Cin + CK - 1) / CK) * 9 * 4 * NF * 64;
   if (ws == nullptr || ws_bytes < nfrag * sizeof(frag_t)) return frl_fail(-4, "conv3x3: workspace too small for the packed weights");
-  FRL_LAUNCH((c3_pack_kernel<T, NF>), dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, (frag_t*)ws, w, so, si, tap_rev, Cin, Cout);
+  const frag_t* pk = (const frag_t*)ws;                            // packed weights: this call's workspace, or the caller's image cache
+  {
+    const FrlPackJob job = frl_pack_job_c3(w, 0, DT<T>::ID, NF, Cout, Cin, so, si, tap_rev, (int)nfrag);
+    bool hit = false;
+    if (void* img = frl_pack_cached(&job, 1, nfrag * sizeof(frag_t), &hit)) pk = (const frag_t*)img;
+    if (!hit) FRL_LAUNCH((c3_pack_kernel<T, NF>), dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, (frag_t*)pk, w, so, si, tap_rev, Cin, Cout);
+  }
   const size_t lds = (size_t)(C3F_TH + 2) * C3_WP * (CK + C3<T>::PADE) * sizeof(T) + (size_t)9 * 4 * NF * 64 * sizeof(frag_t) +
                      (size_t)((Cout + 15) / 16 * 16) * sizeof(float);
   if (lds > 160 * 1024) return frl_fail(-3, "conv3x3: LDS budget exceeded");
@@ -521,7 +528,7 @@ static int launch_c3(const void* x, const void* xm, int mask_act, const float* w
   FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int tiles = B * ((H + C3F_TH - 1) / C3F_TH) * ((W + C3_TW - 1) / C3_TW);
   const int grid = tiles < 256 ? tiles : 256;                  // LDS allows one workgroup per CU: persistent over the tiles
-  FRL_LAUNCH_AS("conv3x3_kernel", kern, dim3(grid), dim3(512), lds, st, (const T*)x, (const T*)xm, mask_act, (const frag_t*)ws, bias, (T*)y, B,
+  FRL_LAUNCH_AS("conv3x3_kernel", kern, dim3(grid), dim3(512), lds, st, (const T*)x, (const T*)xm, mask_act, pk, bias, (T*)y, B,
                      H, W, Cin, Cout, act);
   return frl_check_launch("conv3x3");
 }

@@ -7,6 +7,7 @@
 // the kernel (LDS tiles + ds_read_b64_tr_b16 fragments; every wave owns a block-row of dW2 / dW1), as tcn_fused.hip does.
 #include "frl_common.hpp"
 #include "frl_host.hpp"
+#include "frl_pack.hpp"
 #include "frl_reduce.hpp"
 
 typedef bf16 TT;
@@ -293,6 +294,31 @@ __global__ void dec_pack_kernel(frag8* __restrict__ dst, const float* __restrict
   pack_weights_lds<TT, 4>(p, W1, Cz, DF_H, CB, 1, Cz, tid, nt);                          // dz[o=c] = sum_h W1[h][c] dh[h]
 }
 
+// Packed image of the decoder weights (layout of dec_pack_kernel): from the caller's image cache when one is active, else packed into `ws_pk`.
+template <int NFZ>
+static const frag8* dec_packed(const float* w1, const float* w2, int Cz, int bwd, frag8* ws_pk, hipStream_t st) {
+  constexpr int CZP = 32 * NFZ, CB = CZP / 16;
+  FrlPackJob jobs[4];
+  size_t off = 0;
+  jobs[0] = frl_pack_job_pw(w1, off, FRL_BF16, NFZ, DF_H, Cz, 8, Cz, 1);
+  off += (size_t)8 * NFZ * 64 * sizeof(frag8);
+  jobs[1] = frl_pack_job_pw(w2, off, FRL_BF16, 4, DF_F, DF_H, 4, DF_H, 1);
+  off += (size_t)16 * 64 * sizeof(frag8);
+  int n = 2;
+  if (bwd) {
+    jobs[2] = frl_pack_job_pw(w2, off, FRL_BF16, 2, DF_H, DF_F, 8, 1, DF_H);
+    off += (size_t)16 * 64 * sizeof(frag8);
+    jobs[3] = frl_pack_job_pw(w1, off, FRL_BF16, 4, Cz, DF_H, CB, 1, Cz);
+    off += (size_t)CB * 4 * 64 * sizeof(frag8);
+    n = 4;
+  }
+  bool hit = false;
+  frag8* pk = ws_pk;
+  if (void* img = frl_pack_cached(jobs, n, off, &hit)) pk = (frag8*)img;
+  if (!hit) FRL_LAUNCH((dec_pack_kernel<NFZ>), dim3(32), dim3(256), 0, st, pk, w1, w2, Cz, bwd);
+  return pk;
+}
+
 template <int NFZ>
 struct DecEpi {
   float *dW2, *dW1, *db2, *db1; int Cz;
@@ -316,8 +342,7 @@ static int launch_dec_bwd(const void* z, const float* w1, const float* b1, const
   constexpr int CZP = 32 * NFZ, CB = CZP / 16, R = 16 * NW;
   const unsigned grid = df_bwd_grid(P, R);
   const size_t slab_n = (size_t)DF_F * DF_H + DF_H * CZP + DF_F + DF_H;
-  frag8* pk = reinterpret_cast<frag8*>(ws + ((grid * slab_n * sizeof(float) + 255) / 256) * 256);
-  FRL_LAUNCH((dec_pack_kernel<NFZ>), dim3(32), dim3(256), 0, st, pk, w1, w2, Cz, 1);
+  const frag8* pk = dec_packed<NFZ>(w1, w2, Cz, 1, reinterpret_cast<frag8*>(ws + ((grid * slab_n * sizeof(float) + 255) / 256) * 256), st);
   const size_t lds = (size_t)(8 * NFZ + 16 + 16 + CB * 4) * 64 * sizeof(frag8) + 192 * sizeof(float) +
                      (size_t)R * ((DF_F + 8) + 2 * (DF_H + 8) + (CZP + 8)) * sizeof(TT);
   auto kern = dec_mse_bwd_kernel<NFZ, NW>;
@@ -352,15 +377,15 @@ int frl_decoder_mse_fwd(const void* z, const float* w1, const float* b1, const f
   if (ws_bytes < frl_decoder_mse_workspace_bytes(P, Cz)) return frl_fail(-4, "decoder_mse_fwd: workspace too small");
   char* w = (char*)ws;
   double* partial = (double*)w;
-  frag8* pk = reinterpret_cast<frag8*>(w + (size_t)DF_GRID_MAX * 2 * sizeof(double) + 256);
+  frag8* ws_pk = reinterpret_cast<frag8*>(w + (size_t)DF_GRID_MAX * 2 * sizeof(double) + 256);
   const unsigned grid = df_fwd_grid(P);
   if (Cz <= 32) {
-    FRL_LAUNCH((dec_pack_kernel<1>), dim3(32), dim3(256), 0, stream, pk, w1, w2, Cz, 0);
+    const frag8* pk = dec_packed<1>(w1, w2, Cz, 0, ws_pk, stream);
     const size_t lds = (size_t)(8 + 16) * 64 * sizeof(frag8) + 192 * sizeof(float);
     FRL_LAUNCH((dec_mse_fwd_kernel<1>), dim3(grid), dim3(256), lds, stream, (const TT*)z, (const frag8*)pk, b1, b2, (const TT*)target, mask,
                (TT*)xhat, P, Cz, partial);
   } else {
-    FRL_LAUNCH((dec_pack_kernel<2>), dim3(32), dim3(256), 0, stream, pk, w1, w2, Cz, 0);
+    const frag8* pk = dec_packed<2>(w1, w2, Cz, 0, ws_pk, stream);
     const size_t lds = (size_t)(16 + 16) * 64 * sizeof(frag8) + 192 * sizeof(float);
     FRL_LAUNCH((dec_mse_fwd_kernel<2>), dim3(grid), dim3(256), lds, stream, (const TT*)z, (const frag8*)pk, b1, b2, (const TT*)target, mask,
                (TT*)xhat, P, Cz, partial);

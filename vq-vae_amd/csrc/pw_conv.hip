@@ -9,6 +9,7 @@
 // Roofline: HBM-bound (AI = 2*Cin*Cout/((Cin+Cout)*s) = 42 FLOP/B for 64->128 bf16 vs 312 balance).
 #include "frl_common.hpp"
 #include "frl_host.hpp"
+#include "frl_pack.hpp"
 
 template <typename T, int NF, int NT>
 __global__ __launch_bounds__(256) void pw_conv_kernel(
@@ -131,7 +132,13 @@ static int launch_pw(const void* x, const void* xmask, int mask_act, const float
   const size_t lds = wbytes + (size_t)16 * MB * sizeof(float);
   if (lds > 160 * 1024) return frl_fail(-3, "pw_conv: weights exceed LDS (Cin*Cout too large)");
   if (ws == nullptr || ws_bytes < wbytes) return frl_fail(-4, "pw_conv: workspace too small for the packed weights");
-  FRL_LAUNCH((pack_weights_kernel<T, NF>), dim3((MB * NF * 64 + 255) / 256), dim3(256), 0, st, (frag_t*)ws, w, Cout, Cin, MB, so, si);
+  const frag_t* pk = (const frag_t*)ws;                            // packed weights: this call's workspace, or the caller's image cache
+  {
+    const FrlPackJob job = frl_pack_job_pw(w, 0, DT<T>::ID, NF, Cout, Cin, MB, so, si);
+    bool hit = false;
+    if (void* img = frl_pack_cached(&job, 1, wbytes, &hit)) pk = (const frag_t*)img;
+    if (!hit) FRL_LAUNCH((pack_weights_kernel<T, NF>), dim3((MB * NF * 64 + 255) / 256), dim3(256), 0, st, (frag_t*)pk, w, Cout, Cin, MB, so, si);
+  }
   auto kern = pw_conv_kernel<T, NF, NT>;
   if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t ngroups = ((P + 15) / 16 + NT - 1) / NT;
@@ -139,7 +146,7 @@ static int launch_pw(const void* x, const void* xmask, int mask_act, const float
   if (grid > 4096) grid = 4096;
   if (grid < 1) grid = 1;
   FRL_LAUNCH_AS("pw_conv_kernel", kern, dim3((unsigned)grid), dim3(256), lds, st, (const T*)x, (const T*)xmask, mask_act,
-             (const frag_t*)ws, bias, (T*)y, P, Cin, Cout, act);
+             pk, bias, (T*)y, P, Cin, Cout, act);
   return frl_check_launch("pw_conv");
 }
 

@@ -639,6 +639,21 @@ static int th_launch_bwd(const void* x, const void* mask, const void* dy, const 
 
 static int g_th_force_bwd2 = 0;
 
+// Packed image of one block (layout of tcn_hot_pack_kernel): from the caller's image cache when one is active, else packed into `ws_pk`.
+static const frag8* th_packed(const float* conv_w, const float* gate_w, frag8* ws_pk, hipStream_t stream) {
+  FrlPackJob jobs[8];
+  const size_t blk = (size_t)4 * 2 * 64 * sizeof(frag8);          // one [4][2][64] fragment block
+  for (int k = 0; k < 3; ++k) jobs[k] = frl_pack_job_pw(conv_w + k, k * blk, FRL_BF16, 2, 64, 64, 4, 64 * 3, 3);
+  jobs[3] = frl_pack_job_pw(gate_w, 3 * blk, FRL_BF16, 2, 64, 64, 4, 64, 1);
+  jobs[4] = frl_pack_job_pw(gate_w, 4 * blk, FRL_BF16, 2, 64, 64, 4, 1, 64);
+  for (int k = 0; k < 3; ++k) jobs[5 + k] = frl_pack_job_pw(conv_w + k, (5 + k) * blk, FRL_BF16, 2, 64, 64, 4, 3, 64 * 3);
+  bool hit = false;
+  frag8* pk = ws_pk;
+  if (void* img = frl_pack_cached(jobs, 8, TH_PACK_BYTES, &hit)) pk = (frag8*)img;
+  if (!hit) FRL_LAUNCH(tcn_hot_pack_kernel, dim3(32), dim3(256), 0, stream, pk, conv_w, gate_w);
+  return pk;
+}
+
 extern "C" {
 
 // test hook: 1 routes every hot backward through the 8-wave kernel of this file (mask / ragged-tile path), 0 restores the dispatch
@@ -659,8 +674,7 @@ int frl_tcn_hot_fwd(const void* x, const void* drop_mask, const float* conv_w, c
                     hipStream_t stream) {
   if (npix <= 0 || HW <= 0) return frl_fail(-2, "tcn_hot_fwd: empty input");
   if (ws == nullptr || ws_bytes < TH_PACK_BYTES) return frl_fail(-4, "tcn_hot_fwd: workspace too small");
-  frag8* pk = (frag8*)ws;
-  FRL_LAUNCH(tcn_hot_pack_kernel, dim3(32), dim3(256), 0, stream, pk, conv_w, gate_w);
+  const frag8* pk = th_packed(conv_w, gate_w, (frag8*)ws, stream);
   int rc = -2;
   if (dilation == 1) rc = th_launch_fwd<1>(x, drop_mask, pk, conv_b, gn_w, gn_b, gate_b, y, npix, HW, eps, stream);
   else if (dilation == 2) rc = th_launch_fwd<2>(x, drop_mask, pk, conv_b, gn_w, gn_b, gate_b, y, npix, HW, eps, stream);
@@ -680,8 +694,8 @@ int frl_tcn_hot_bwd(const void* x, const void* drop_mask, const void* dy, const 
   if (ws == nullptr || ws_bytes < frl_tcn_hot_bwd_workspace_bytes(npix)) return frl_fail(-4, "tcn_hot_bwd: workspace too small");
   const unsigned grid = th_bwd_grid(npix);
   float* slab = (float*)ws;
-  frag8* pk = reinterpret_cast<frag8*>(reinterpret_cast<char*>(ws) + (((size_t)grid * TH_SLAB * sizeof(float) + 255) / 256) * 256);
-  FRL_LAUNCH(tcn_hot_pack_kernel, dim3(32), dim3(256), 0, stream, pk, conv_w, gate_w);
+  const frag8* pk = th_packed(conv_w, gate_w,
+                              reinterpret_cast<frag8*>(reinterpret_cast<char*>(ws) + (((size_t)grid * TH_SLAB * sizeof(float) + 255) / 256) * 256), stream);
   int rc = -2;
   if (drop_mask == nullptr && th_bwd3_supported(npix, HW) && !g_th_force_bwd2)      // the measured configuration: tcn_hot_bwd3.hip
     rc = th_bwd3_launch(dilation, x, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);

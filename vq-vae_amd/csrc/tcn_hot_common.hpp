@@ -3,6 +3,7 @@
 #pragma once
 #include "tcn_common.hpp"
 #include "frl_host.hpp"
+#include "frl_pack.hpp"
 #include "frl_reduce.hpp"
 
 #define TH_T 5

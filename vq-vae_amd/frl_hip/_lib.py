@@ -30,6 +30,12 @@ SIGNATURES = {
     "frl_device_arch": (c_int, [c_char_p, I]),
     "frl_kernel_timing_enable": (c_int, [I]),
     "frl_kernel_timing_report": (c_int, [c_char_p, I]),
+    "frl_pack_cache_table_bytes": (S, []),
+    "frl_pack_cache_create": (c_int, [P, S]),
+    "frl_pack_cache_destroy": (c_int, [I]),
+    "frl_pack_cache_activate": (c_int, [I]),
+    "frl_pack_cache_images": (c_int, [I]),
+    "frl_pack_cache_refresh": (c_int, [I, P]),
     "frl_conv_workspace_bytes": (S, [I, I, I]),
     "frl_conv1x1_fwd": (c_int, [P, P, P, P, L, I, I, I, I, P, S, P]),
     "frl_conv1x1_bwd_data": (c_int, [P, P, I, P, P, L, I, I, I, P, S, P]),

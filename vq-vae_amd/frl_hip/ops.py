@@ -48,6 +48,45 @@ def kernel_timing_report():
     return out
 
 
+class PackCache:
+    """Weight-image cache of a trainer (include/frl_hip.h: frl_pack_cache_*): the packed MFMA fragment images of the model's weights live
+    in an arena owned by this object; `with cache:` makes the conv-like calls use them, `refresh()` rewrites all of them in one launch."""
+
+    def __init__(self, device, nbytes: int = 64 << 20):
+        lib = _lib.load()
+        self.arena = torch.empty(int(nbytes) + lib.frl_pack_cache_table_bytes(), dtype=torch.uint8, device=device)
+        self.handle = lib.frl_pack_cache_create(ctypes.c_void_p(self.arena.data_ptr()), self.arena.numel())
+        if self.handle <= 0:
+            check(self.handle, "frl_pack_cache_create")
+        self._prev = 0
+
+    def __enter__(self):
+        self._prev = _lib.load().frl_pack_cache_activate(self.handle)
+        return self
+
+    def __exit__(self, *a):
+        _lib.load().frl_pack_cache_activate(self._prev)
+        return False
+
+    def refresh(self) -> None:
+        check(_lib.load().frl_pack_cache_refresh(self.handle, _stream()), "frl_pack_cache_refresh")
+
+    @property
+    def images(self) -> int:
+        return _lib.load().frl_pack_cache_images(self.handle)
+
+    def close(self) -> None:
+        if self.handle > 0:
+            _lib.load().frl_pack_cache_destroy(self.handle)
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class span:
     """with ops.span("name"): ...  -- HIP-event timing of a sub-range (used for single-kernel roofline numbers)."""
 

@@ -19,7 +19,8 @@ from .schedules import LambdaVQSchedule, beta_schedule, cosine_lr
 class VQVAETrainer:
     def __init__(self, model, lr: float = 1e-4, min_lr: float = 1e-6, weight_decay: float = 0.01, max_norm: float = 1.0,
                  total_steps: int = 1000, betas=(0.9, 0.95), check_finite: bool = True, fused_optimizer: bool = True,
-                 beta_schedule_cfg: Optional[dict] = None, lambda_vq_schedule: Optional[LambdaVQSchedule] = None):
+                 beta_schedule_cfg: Optional[dict] = None, lambda_vq_schedule: Optional[LambdaVQSchedule] = None,
+                 pack_cache: bool = True):
         self.model = model
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         cb = [p for n, p in named if "quant" in n and "codebook" in n]
@@ -35,6 +36,13 @@ class VQVAETrainer:
         else:
             self.opt = torch.optim.AdamW(groups, lr=lr, betas=betas)
         self.params = [p for _, p in named]
+        # Weight-image cache (ops.PackCache): the packed MFMA fragment images of all conv weights live in an arena of this trainer; the
+        # calls of a step find them there (no per-call packing launch) and ONE launch behind the optimizer rewrites all of them.
+        self.pack_cache = None
+        self._pack_versions = None
+        if pack_cache and self.hip_opt:
+            from .. import ops
+            self.pack_cache = ops.PackCache(rest[0].device)
         self.lr, self.min_lr, self.total_steps, self.max_norm = lr, min_lr, total_steps, max_norm
         self.check_finite = check_finite
         self.beta_schedule_cfg = beta_schedule_cfg
@@ -196,6 +204,7 @@ class VQVAETrainer:
                 b.copy_(q)
         o.step_count, o.lag = st["step_count"], list(st["lag"])
         o._key = None
+        self._images_refresh()                                     # the weight images follow the restored parameters
         mgr = getattr(m, "codebook_manager", None)
         if mgr is not None and "window" in st:
             mgr.window.copy_(st["window"])
@@ -210,16 +219,38 @@ class VQVAETrainer:
                     qz._prepared = ((None, None, dtype), qz._prepared[1])
                     qz.prepared(dtype, 1 << 20)
 
+    def _images_current(self) -> None:
+        """Weights modified by anyone but this trainer's optimizer since the last step (load_state_dict, manual edits): rewrite the images."""
+        if self.pack_cache is None:
+            return
+        vers = [p._version for p in self.params]
+        if vers != self._pack_versions:
+            self.pack_cache.refresh()
+            self._pack_versions = vers
+
+    def _images_refresh(self) -> None:
+        if self.pack_cache is not None:
+            self.pack_cache.refresh()
+            self._pack_versions = [p._version for p in self.params]
+
     def _step_body(self, tile, mask):
         """forward -> device isfinite flag -> backward -> clip + AdamW -> codebook hooks -> fragment-image refresh (no host-side
         schedule, no host sync): the part of `step` that a graph can hold."""
         self.model.train()
         self.opt.zero_grad(set_to_none=True)
-        out = self.model.forward_tiles(tile, mask)
-        loss = out["loss"]
-        ok = (loss.detach().float() * 0.0 == 0.0).float().reshape(1)
-        loss.backward()
+        if self.pack_cache is not None:
+            with self.pack_cache:
+                out = self.model.forward_tiles(tile, mask)
+                loss = out["loss"]
+                ok = (loss.detach().float() * 0.0 == 0.0).float().reshape(1)
+                loss.backward()
+        else:
+            out = self.model.forward_tiles(tile, mask)
+            loss = out["loss"]
+            ok = (loss.detach().float() * 0.0 == 0.0).float().reshape(1)
+            loss.backward()
         out["grad_norm"] = self.opt.step(self.max_norm, None, ok)
+        self._images_refresh()
         if getattr(self.model, "defer_codebook_hooks", False):
             self.model.commit_codebook_hooks(ok)
         if hasattr(self.model, "_quantizers"):
@@ -238,6 +269,16 @@ class VQVAETrainer:
             self.model.lambda_vq = self.lambda_vq_schedule(self.step_idx)
         self.model.train()
         self.opt.zero_grad(set_to_none=True)
+        self._images_current()
+        if self.pack_cache is not None:
+            self.pack_cache.__enter__()
+        try:
+            return self._step_eager(tile, mask, lr_now)
+        finally:
+            if self.pack_cache is not None:
+                self.pack_cache.__exit__(None, None, None)
+
+    def _step_eager(self, tile, mask, lr_now):
         out = self.model.forward_tiles(tile, mask)
         loss = out["loss"]
         ok = None
@@ -271,6 +312,7 @@ class VQVAETrainer:
                 if ok is not None:
                     ok = (self.reducer.flag_result() == 0).float()   # 1 <=> no rank reported a non-finite loss
             out["grad_norm"] = self.opt.step(self.max_norm, grads, ok)
+            self._images_refresh()
             if getattr(self.model, "defer_codebook_hooks", False):
                 self.model.commit_codebook_hooks(ok)                   # EMA / usage window: gated by the same device flag
         else:
