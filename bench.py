@@ -294,7 +294,14 @@ def main():
         flops = 3 * conv_flops_per_tile(args.time, args.size, args.features, args.emb_dim, model.z_phase_dim) * args.batch
         out["conv_mfma"] = {"TFLOP/s": round(flops / conv_ms / 1e9, 1), "frac": round(flops / conv_ms / 1e9 / MFMA_BF16_PEAK_TF, 4),
                             "ms_per_step": round(conv_ms, 3), "GFLOP_per_step": round(flops / 1e9, 1),
-                            "note": "algorithmic 3x-forward dense FLOPs / HIP-event time of all conv + TCN ops"}
+                            "note": "algorithmic 3x-forward dense FLOPs / HIP-event time of all conv + TCN ops (C-ABI call spans: "
+                                    "slab reductions and launch gaps of each call included)"}
+        # the same FLOPs over the contraction kernels alone (library-side event pairs around each launch)
+        mm = ("tcn_hot", "pw_conv", "pw_wgrad", "conv3x3", "dec_mse_fwd", "dec_mse_bwd")
+        mm_ms = sum(ms for k, (_, ms) in kern.items() if any(t in k for t in mm)) / args.steps
+        if mm_ms > 0:
+            out["conv_mfma"]["kernels_only"] = {"TFLOP/s": round(flops / mm_ms / 1e9, 1), "ms_per_step": round(mm_ms, 3),
+                                                "frac": round(flops / mm_ms / 1e9 / MFMA_BF16_PEAK_TF, 4)}
         mu = mfma_util_from_profiles()
         if mu:
             out["conv_mfma"]["mfma_util"] = mu
@@ -350,14 +357,14 @@ def profiled_kernel_us(substr):
 
 def pmc_traffic(name):
     """HBM bytes per launch from the newest committed rocprofv3 --pmc passes (profiles/*_pmc.json), or None."""
-    key = {"tcn_block_bwd.main": "tcn_hot_bwd2_kernel", "tcn_block_fwd": "tcn_hot_fwd_kernel", "vq_assign": "vq_assign_kernel",
+    key = {"tcn_block_bwd.main": "tcn_hot_bwd", "tcn_block_fwd": "tcn_hot_fwd_kernel", "vq_assign": "vq_assign_kernel",
            "edge_smooth_bwd": "smooth_bwd_bf16r4_kernel", "conv1x1_bwd_weight": "pw_wgrad_kernel"}.get(name)
     try:
         import glob
         f = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))[-1]
-        for k, v in json.load(open(f))["kernels"].items():
-            if key and key in k:
-                return v["hbm_bytes_per_launch"]
+        hit = [v["hbm_bytes_per_launch"] for k, v in json.load(open(f))["kernels"].items() if key and key in k]
+        if hit:                                                     # the template instances of one family (dilation 1 / 2 / 4) averaged
+            return int(sum(hit) / len(hit))
     except Exception:
         pass
     return None

@@ -62,6 +62,34 @@ def main():
                        "--no-kernel-timing --serial-streams`; values in KiB averaged over the launches of each kernel; hbm_bytes_per_launch = (2*FETCH_SIZE + "
                        "WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 128-B requests of wide coalesced reads as 64 B, MI355X_MICROARCH.md)",
                "kernels": ks}, open(f"profiles/{name}_pmc.json", "w"), indent=1)
+    sqdb = os.path.join(src, "pmc_sq", "run_results.db")
+    if os.path.exists(sqdb):
+        names = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE")
+        per = {n: pmc(sqdb, n) for n in names}
+        out = {}
+        for k in sorted(set().union(*[set(v) for v in per.values()])):
+            row = {n: per[n][k][1] for n in names if k in per[n]}
+            if row.get("GRBM_GUI_ACTIVE", 0) > 0 and "SQ_VALU_MFMA_BUSY_CYCLES" in row:
+                cycles = row["GRBM_GUI_ACTIVE"] / 8.0                       # the counter is the sum over the 8 XCDs
+                row["kernel_cycles"] = round(cycles, 1)
+                row["mfma_util"] = round(row["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024.0), 4)      # 256 CUs x 4 SIMDs
+                if row.get("SQ_WAVE_CYCLES", 0) > 0:
+                    row["wave_time_waiting"] = round(row.get("SQ_WAIT_ANY", 0.0) / row["SQ_WAVE_CYCLES"], 3)
+            out[k] = {kk: (round(vv, 1) if isinstance(vv, float) else vv) for kk, vv in row.items()}
+        conv = {}
+        for fam, subs in (("tcn_hot_bwd", ("tcn_hot_bwd",)), ("tcn_hot_fwd", ("tcn_hot_fwd",)), ("conv3x3", ("conv3x3_kernel",)),
+                          ("conv3x3_wgrad", ("conv3x3_wgrad",)), ("pw_conv", ("pw_conv_kernel",)), ("pw_wgrad", ("pw_wgrad",)),
+                          ("dec_mse", ("dec_mse_",)), ("vq_assign", ("vq_assign",))):
+            hits = [v for k, v in out.items() if any(s in k for s in subs) and "mfma_util" in v]
+            if hits:
+                busy = sum(h["SQ_VALU_MFMA_BUSY_CYCLES"] for h in hits)
+                cyc = sum(h["kernel_cycles"] for h in hits)
+                conv[fam] = round(busy / (cyc * 1024.0), 4)
+        json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE "
+                           "-- python3 bench.py --steps 2 --warmup 1 --no-kernel-timing --no-cpu-baseline --serial-streams --graph off; averages per "
+                           "launch; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs): the share of SIMD cycles with the "
+                           "matrix pipe busy (16 cycles per v_mfma_f32_16x16x32_bf16)",
+                   "kernels": conv, "per_kernel": out}, open(f"profiles/{name}_mfma_util.json", "w"), indent=1)
     if os.path.exists(os.path.join(src, "bench.json")):
         shutil.copy(os.path.join(src, "bench.json"), f"profiles/{name}_bench.json")
     print(f"wrote profiles/{name}_kernel_stats.md/.csv, profiles/{name}_pmc.json; total {tot / 30:.3f} ms/step")
