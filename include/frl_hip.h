@@ -242,12 +242,14 @@ int frl_vq_assign_fwd(const void* z, const float* E, int64_t N, int K, int d, in
                       float* stats_out, int32_t* counts_out, int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
 /* Prepared codebook (||e||^2 + the packed MFMA fragment image of -2 e): it depends on the codebook content and dtype only, so a
  * caller that knows when the codebook changes (once per optimizer step; never during inference) builds it once and the assignment
- * itself is ONE kernel launch behind a memset node: arg-min on the matrix cores, exact float64 re-evaluation of near-ties while the
- * codebook is still in LDS, z_q gather, squared error, code histogram (integer atomics) and the statistics (folded by the workgroup
- * that arrives last) -- when the codebook fits one LDS chunk (K * d_pad * sizeof(dtype) <= 64 KB), else as frl_vq_assign_fwd. */
+ * itself is ONE kernel launch with nothing to zero beforehand: arg-min on the matrix cores, exact float64 re-evaluation of near-ties
+ * while the codebook is still in LDS, z_q, squared error, code histogram (integer atomics) and the statistics (folded by the workgroup
+ * that arrives last) -- when the codebook fits one LDS chunk (K * d_pad * sizeof(dtype) <= 64 KB), else as frl_vq_assign_fwd.
+ * The image also holds the kernel's arrival counter and histogram accumulator (zeroed by frl_vq_prepare and left zeroed by every
+ * call), so at most ONE assignment may be in flight per prepared image. */
 size_t frl_vq_prepared_bytes(int K, int d);
 int frl_vq_prepare(const float* E, int64_t N, int K, int d, int dtype, void* prep, size_t prep_bytes, frl_stream_t stream);
-int frl_vq_assign_fwd_prepared(const void* z, const float* E, const void* prep /* NULL: prepare inside the call */, int64_t N, int K, int d,
+int frl_vq_assign_fwd_prepared(const void* z, const float* E, void* prep /* NULL: prepare inside the call */, int64_t N, int K, int d,
                                int32_t* idx_out, void* zq_out, float* stats_out, int32_t* counts_out, int dtype, void* ws,
                                size_t ws_bytes, frl_stream_t stream);
 int frl_vq_bwd(const void* g_out, const void* z, const void* zq /* optional */, const float* E, const int32_t* idx, const int32_t* counts,

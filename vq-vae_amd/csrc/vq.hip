@@ -25,7 +25,7 @@
 #define VQ_MAX_CHUNK 512
 
 struct VqHeader {           // lives at the start of the workspace (zeroed by hipMemsetAsync every call)
-  unsigned enmax_bits;      // max_k ||e_k||^2 as f32 bits (atomicMax on positive floats; multi-chunk path)
+  unsigned enmax_bits;      // (unused; kept for the layout)
   int namb;                 // number of rows flagged for exact re-evaluation (append counter of amb_list / total of the fused path)
   double sq_fix;            // sum of squared errors of the re-evaluated rows (multi-chunk path)
   int done;                 // fused path: workgroups that have published their partial results (arrival ticket)
@@ -36,12 +36,14 @@ struct VqHeader {           // lives at the start of the workspace (zeroed by hi
 // [en: kpad floats][packed fragments] that frl_vq_prepare hands to the caller, who keeps it until the codebook changes
 template <typename T, int NF>
 __global__ void vq_prepare_kernel(const float* __restrict__ E, int K, int d, float* __restrict__ en, int kpad,
-                                  typename DT<T>::frag_t* __restrict__ pk, int total, int npack_blocks) {
+                                  typename DT<T>::frag_t* __restrict__ pk, int total, int npack_blocks, int* __restrict__ ctl) {
   constexpr int FE = DT<T>::FE;
   constexpr int q = NF * FE;
   if ((int)blockIdx.x >= npack_blocks) {
     const int k = ((int)blockIdx.x - npack_blocks) * blockDim.x + threadIdx.x;
     if (k >= kpad) return;
+    if (k < 64) ctl[k] = 0;                                  // control block of the resident kernel: {done, namb, ...}, counts_acc[K]
+    if (k < K) ctl[64 + k] = 0;
     float s = 3.0e38f;                                     // codes beyond K never win
     if (k < K) {
       s = 0.f;
@@ -83,7 +85,7 @@ __device__ unsigned long long* vq_dbg;      // diagnostic build only (tools/diag
 // exact squared distances of row n to the codes k0 and k1 (k1 < 0: only k0) in float64; operands rounded to T first, as everywhere
 // in this file.  16-byte loads, four chunks in flight: the caller is one lane per candidate pair, the latency of the loads is all
 // there is to hide.
-template <typename T>
+template <typename T, int U = 4>
 __device__ __forceinline__ void vq_exact_pair(const T* __restrict__ Z, const float* __restrict__ E, int64_t n, int k0, int k1, int d,
                                               double& d0, double& d1) {
   const T* zr = Z + n * (int64_t)d;
@@ -91,7 +93,7 @@ __device__ __forceinline__ void vq_exact_pair(const T* __restrict__ Z, const flo
   const float* e1 = E + (int64_t)(k1 >= 0 ? k1 : k0) * d;
   double s0 = 0.0, s1 = 0.0;
   if ((d & 7) == 0) {
-#pragma unroll 4
+#pragma unroll U
     for (int j = 0; j < d; j += 8) {
       float zv[8];
       if constexpr (sizeof(T) == 2) {
@@ -107,39 +109,30 @@ __device__ __forceinline__ void vq_exact_pair(const T* __restrict__ Z, const flo
         const double zz = (double)zv[e];
         const double da = zz - (double)to_f32(from_f32<T>(e < 4 ? a0[e & 3] : a1[e & 3]));
         const double db = zz - (double)to_f32(from_f32<T>(e < 4 ? b0[e & 3] : b1[e & 3]));
-        s0 += da * da;
-        s1 += db * db;
+        s0 = __builtin_fma(da, da, s0);
+        s1 = __builtin_fma(db, db, s1);
       }
     }
   } else {
     for (int j = 0; j < d; ++j) {
       const double zz = (double)to_f32(zr[j]);
       const double da = zz - (double)to_f32(from_f32<T>(e0[j])), db = zz - (double)to_f32(from_f32<T>(e1[j]));
-      s0 += da * da;
-      s1 += db * db;
+      s0 = __builtin_fma(da, da, s0);
+      s1 = __builtin_fma(db, db, s1);
     }
   }
   d0 = s0;
   d1 = s1;
 }
 
-#define VQ_AMB_CAP 512      // fused path: capacity of the workgroup's list of rows awaiting the exact re-evaluation (3 ints per row)
-
-// FUSED (single codebook chunk: the whole codebook stays in LDS): ONE launch does everything --
-//   * rows whose two best scores are within the rounding bound are parked in an LDS list and resolved by the workgroup itself while the
-//     codebook is still resident (vq_resolve below: candidates screened on the matrix cores, float64 only for the candidates);
-//   * the code histogram goes from LDS into the global counts with one integer atomic per (workgroup, used code) (integer sums are
-//     order-independent, so the result is still bit-reproducible);
-//   * the workgroup that arrives last (ticket counter behind an agent-scope release / acquire) folds the squared-error partials and
-//     the perplexity and writes stats / counts.
-// The multi-chunk path (K larger than one LDS chunk) keeps the global list + vq_fixup kernels + slab reduction.
-template <typename T, int NF, int NT, int NW, bool FUSED>
+// Multi-chunk assignment (codebook image larger than one LDS chunk): ambiguous rows go to a global list for the vq_fixup kernels,
+// histograms to per-workgroup slabs.  A codebook that fits one chunk takes vq_assign_resident_kernel below.
+template <typename T, int NF, int NT, int NW>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
     const T* __restrict__ Z, const float* __restrict__ E, const float* __restrict__ en_g, const VqHeader* __restrict__ hdr,
     int64_t N, int K, int d, int Kc, int32_t* __restrict__ idx_out, T* __restrict__ zq_out,
     float* __restrict__ partial /*[grid*NW]*/, int32_t* __restrict__ hist_slab /*[grid][K]*/, VqHeader* __restrict__ hdr_w,
-    int32_t* __restrict__ amb_list, const typename DT<T>::frag_t* __restrict__ pk,
-    int32_t* __restrict__ counts_acc, int32_t* __restrict__ counts_out, float* __restrict__ stats_out) {
+    int32_t* __restrict__ amb_list, const typename DT<T>::frag_t* __restrict__ pk) {
   typedef typename DT<T>::frag_t frag_t;
   constexpr int FE = DT<T>::FE;
   constexpr int q = NF * FE;                 // channels per lane quarter
@@ -148,117 +141,30 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
   float* enl = reinterpret_cast<float*>(smem + (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t));  // [Kc]
   int* hist = reinterpret_cast<int*>(enl + Kc);                        // [K]
   unsigned* cbw = reinterpret_cast<unsigned*>(hist + K);               // batch maximum of ||z||^2 (f32 bits), [NW + 1] (+ pad to 32)
-  float* enr = reinterpret_cast<float*>(cbw + 32);                     // FUSED: [Kc] ||e||^2 without the batch bias
-  int* amb_rows = reinterpret_cast<int*>(enr + Kc);                    // FUSED: [VQ_AMB_CAP] x {row low, row high, candidate limit (f32 bits)}
-  int* amb_n = amb_rows + 3 * VQ_AMB_CAP;                              // FUSED: [0] list length, [1] broadcast slot
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vx = lane & 15, kc = lane >> 4;
   const int nchunks = (K + Kc - 1) / Kc;
   const bool fast = (d == 4 * q);
   float enmax;
-  if constexpr (FUSED) {                                               // max ||e||^2 over the real codes, by the workgroup itself
+  {                                                                    // max ||e||^2 over the real codes, by the workgroup itself
     float m = 0.f;
     for (int k = tid; k < K; k += NW * 64) m = fmaxf(m, en_g[k]);
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if (lane == 0) cbw[wave] = __float_as_uint(m);
-    if (tid == 0) { amb_n[0] = 0; amb_n[1] = 0; }
     __syncthreads();
     unsigned mm = 0u;
 #pragma unroll
     for (int w = 0; w < NW; ++w) mm = mm > cbw[w] ? mm : cbw[w];
     enmax = __uint_as_float(mm);
     __syncthreads();
-  } else {
-    enmax = __uint_as_float(hdr->enmax_bits);
   }
   const float err_rel = (float)(4 * q + 8) * 1.1920929e-7f;            // (d_pad+8) * 2^-23: f32 accumulation of exact products
   const float thr_rel = 3.0517578125e-5f + 2.f * err_rel;              // 2^-(22-7) key truncation of both scores + 2*err
 
-#ifdef VQ_STAMPS
-  __shared__ unsigned long long vq_ts[16][8];
-  if (tid < 128) (&vq_ts[0][0])[tid] = 0ull;
-  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
-#define VQ_ST(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); if (lane == 0) vq_ts[wave][i] += t_now - t_prev; t_prev = t_now; } while (0)
-#else
-#define VQ_ST(i) do { } while (0)
-#endif
   for (int k = tid; k < K; k += NW * 64) hist[k] = 0;
   float sq_acc = 0.f;
   int filled_chunk = -1;
-
-  // ---- FUSED: exact re-evaluation of the parked rows by the workgroup itself (the whole codebook is resident: Kc >= K).
-  // One wave per tile of 16 parked rows: pass 1 finds the smallest f32 score of every row on the matrix cores, pass 2 re-scores and
-  // keeps every code within the rounding bound of it (the float64 arg-min is provably among them); those few candidates are
-  // evaluated in float64 (up to two pending per lane, flushed together so that the 64-element loops of all lanes run side by side);
-  // first index wins ties.  Then z_q, the squared error and the histogram of these rows are written like those of the main path.
-  int n_resolved = 0;
-  auto resolve = [&]() {
-    if constexpr (FUSED) {
-      const int n = amb_n[0];
-      const int nmb = Kc / 16;
-      for (int t0 = wave * 16; t0 < n; t0 += NW * 16) {
-        const int li = t0 + vx;
-        const bool valid = li < n;
-        const int* ent = amb_rows + 3 * (valid ? li : t0);
-        const int64_t row = ((int64_t)(unsigned)ent[1] << 32) | (unsigned)ent[0];
-        // every code whose (bias-free) f32 score is <= lim may be the float64 arg-min; lim was fixed by the main pass from the row's
-        // best key, the key truncation and the rounding bound of both passes
-        const float lim = __int_as_float(ent[2]);
-        LQTile<T, NF> zr;
-        lq_load<T, NF>(zr, Z, row, d, kc, fast);
-        double best = 1.0e300;
-        int bestk = 0x7fffffff, p0 = -1, p1 = -1;
-        auto flush = [&]() {
-          if (p0 >= 0) {
-            double d0, d1;
-            vq_exact_pair<T>(Z, E, row, p0, p1, d, d0, d1);
-            if (d0 < best || (d0 == best && p0 < bestk)) { best = d0; bestk = p0; }
-            if (p1 >= 0 && (d1 < best || (d1 == best && p1 < bestk))) { best = d1; bestk = p1; }
-          }
-          p0 = p1 = -1;
-        };
-#pragma unroll 4
-        for (int mb = 0; mb < nmb; ++mb) {
-          f32x4 acc = *reinterpret_cast<const f32x4*>(enr + mb * 16 + 4 * kc);
-#pragma unroll
-          for (int s = 0; s < NF; ++s) acc = mfma16(wl[(mb * NF + s) * 64 + lane], zr.f[s], acc);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int code = mb * 16 + 4 * kc + r;
-            const bool hit = acc[r] <= lim && code < K;
-            if (__builtin_amdgcn_ballot_w64(hit && p1 >= 0) != 0ull) flush();       // a lane with both slots taken: evaluate all pending
-            if (hit) { if (p0 < 0) p0 = code; else p1 = code; }
-          }
-        }
-        flush();
-#pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
-          const double ob = __shfl_xor(best, off, 64);
-          const int okk = __shfl_xor(bestk, off, 64);
-          if (ob < best || (ob == best && okk < bestk)) { best = ob; bestk = okk; }
-        }
-        if (valid) {
-          const float* er = E + (int64_t)bestk * d + q * kc;
-          T* zo = zq_out + row * (int64_t)d + q * kc;
-#pragma unroll
-          for (int s = 0; s < NF * FE; ++s) {
-            if (q * kc + s < d) {
-              const float ev = to_f32(from_f32<T>(er[s]));
-              zo[s] = from_f32<T>(ev);
-              const float df = lq_get<T, NF>(zr, s / FE, s % FE) - ev;
-              sq_acc = fmaf(df, df, sq_acc);
-            }
-          }
-          if (kc == 0) { idx_out[row] = bestk; atomicAdd(&hist[bestk], 1); }
-        }
-      }
-      n_resolved += n;
-      __syncthreads();
-      if (tid == 0) amb_n[0] = 0;
-      __syncthreads();
-    }
-  };
 
   const int64_t vec_per_batch = NW * NT * 16;
   const int64_t nbatch = (N + vec_per_batch - 1) / vec_per_batch;
@@ -284,7 +190,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
       zmax = fmaxf(zmax, zn);
       g1[t] = 0xFFFFFFFFu; g2[t] = 0xFFFFFFFFu; gc[t] = 0;
     }
-    VQ_ST(0);                                                    // z loads issued + norms (includes the load latency)
     // One positive bias per workgroup batch (max ||z||^2 of its 256 vectors, + margin) is folded into the LDS copy of
     // ||e||^2, so the MFMA accumulator is initialised straight from LDS and every score en + Cb - 2 z.e stays > 0.
 #pragma unroll
@@ -306,21 +211,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
 #pragma unroll
       for (int t = 0; t < NT; ++t) thr[t] = tv;
     }
-    VQ_ST(1);                                                    // batch bias: 3 barriers + LDS atomic max
     for (int c = 0; c < nchunks; ++c) {
       {
         __syncthreads();
         const int kbase = c * Kc;
         if (filled_chunk != c) copy_frags_lds<T>(wl, pk + (size_t)(kbase / 16) * NF * 64, (Kc / 16) * NF * 64, tid, NW * 64);
         for (int i = tid; i < Kc; i += NW * 64) enl[i] = (kbase + i < K) ? en_g[kbase + i] + Cb : 3.0e38f;
-        if constexpr (FUSED) {
-          if (filled_chunk != c)
-            for (int i = tid; i < Kc; i += NW * 64) enr[i] = (kbase + i < K) ? en_g[kbase + i] : 3.0e38f;
-        }
         __syncthreads();
         filled_chunk = c;
       }
-      VQ_ST(2);                                                  // codebook chunk / ||e||^2 fill
       const int nmb = Kc / 16;
       for (int g0 = 0; g0 < nmb; g0 += 8) {
         unsigned c1[NT], c2[NT];
@@ -356,7 +255,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
         }
       }
     }
-    VQ_ST(3);                                                    // MFMA + key/min/med3 main loop
     // ---- wave-level min-reduce over the 4 lane groups that share a vector ----
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -377,18 +275,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
       if (row < N) {
         if (kc == 0) {
           idx_out[row] = amb ? (-1 - code) : code;
-          if (amb) {
-            if constexpr (FUSED) {
-              const int pos = atomicAdd(&amb_n[0], 1);                 // < VQ_AMB_CAP: the list is drained before it can overflow
-              // s1 carries the batch bias Cb, the re-evaluation scores do not; thr[t] bounds key truncation + rounding of both
-              const float lim = (s1 - Cb) + thr[t] + 2.3841858e-7f * (s1 + Cb);
-              amb_rows[3 * pos] = (int)(unsigned)(row & 0xffffffffll);
-              amb_rows[3 * pos + 1] = (int)(row >> 32);
-              amb_rows[3 * pos + 2] = __float_as_int(lim);
-            } else {
-              amb_list[atomicAdd(&hdr_w->namb, 1)] = (int32_t)row;
-            }
-          }
+          if (amb) amb_list[atomicAdd(&hdr_w->namb, 1)] = (int32_t)row;
         }
         if (!amb) {
           // gather z_q (rounded to T) for this lane's channel quarter, accumulate squared error
@@ -422,71 +309,468 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
         }
       }
     }
-    VQ_ST(4);                                                    // reduce, ambiguity test, z_q gather / store, histogram
-    if constexpr (FUSED) {                                       // (the tile registers are dead here: the drain costs no spill in the loop)
-      __syncthreads();
-      if (amb_n[0] > VQ_AMB_CAP - (int)vec_per_batch) resolve();  // (uniform) the list could overflow in the next batch: drain it now
-    }
   }
-  if constexpr (FUSED) resolve();                                // (the loop ends behind a barrier)
-  VQ_ST(5);                                                      // fused: exact re-evaluation of the parked rows
   // ---- per-workgroup outputs: wave partials of the squared error, histogram ----
   const float ws_ = wave_sum(sq_acc);
   if (lane == 0) partial[blockIdx.x * NW + wave] = ws_;
   __syncthreads();
-  if constexpr (!FUSED) {
-    for (int k = tid; k < K; k += NW * 64) hist_slab[(int64_t)blockIdx.x * K + k] = hist[k];
-  } else {
-    for (int k = tid; k < K; k += NW * 64) {
-      const int h = hist[k];
-      if (h) atomicAdd(&counts_acc[k], h);                         // device-scope integer atomics: order-independent
+  for (int k = tid; k < K; k += NW * 64) hist_slab[(int64_t)blockIdx.x * K + k] = hist[k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Resident-codebook assignment: the whole codebook image fits one LDS chunk (<= 64 KB: K <= 512 at d = 64 bf16), and ONE launch does
+// everything, with nothing to zero beforehand:
+//   * NO batch bias: score = ||e||^2 - 2 z.e straight from the accumulator; the key (f32 bits & ~127) | index is ordered with the FLOAT
+//     v_min_f32 / v_med3_f32, which order positive and negative keys alike (among equal truncated negative scores the larger index
+//     wins: irrelevant, equal scores are re-evaluated exactly anyway; NaN keys are ignored and leave the row at +inf = ambiguous);
+//     the ambiguity threshold is per row, from the row's own norm;
+//   * rows whose two best scores are within the bound are parked in an LDS list in ROW ORDER (ballot ranks + a prefix over the waves:
+//     the slot of a row does not depend on timing, so the squared-error sum is bit-reproducible) and resolved by the whole workgroup
+//     while the codebook is resident: every wave re-scores the parked rows against its share of the code blocks on the matrix cores and
+//     appends the codes under the row's limit to a candidate list; one LANE per candidate evaluates the float64 distance (vq_exact_one:
+//     same summation order for every candidate, so duplicate codes tie exactly), LDS integer atomics keep the minimum and then the
+//     smallest code among the minima (first index wins);  more than VQ_FAST_ROWS parked rows or more candidates than threads (constructed
+//     inputs: every row a tie) take the sequential per-wave path with the same arithmetic;
+//   * z_q comes from the LDS image (-0.5 x the packed -2e is exact) on the bf16 fast path;
+//   * histogram: integer atomics into the control block of the prepared image; the workgroup that arrives last (ticket behind an
+//     agent-scope release / acquire) folds squared-error partials and perplexity, writes stats / counts and ZEROES the control block
+//     again for the next call (the first zeroing is vq_prepare_kernel's).  One call in flight per prepared image.
+// ---------------------------------------------------------------------------------------------
+#define VQ_FAST_ROWS 128     // parked rows per batch the all-wave path handles (typical: < 1 % of the batch's rows)
+struct VqCtl { int done; int namb; int pad[62]; };       // 256 bytes, followed by counts_acc[K]
+
+template <typename T>
+__device__ __forceinline__ double vq_exact_one(const T* __restrict__ Z, const float* __restrict__ E, int64_t n, int k, int d) {
+  double d0, d1;
+  vq_exact_pair<T, 4>(Z, E, n, k, -1, d, d0, d1);        // (k1 < 0: the second row folds away; two 16-byte chunks in flight)
+  return d0;
+}
+
+template <typename T, int NF, int NT, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_resident_kernel(
+    const T* __restrict__ Z, const float* __restrict__ E, const float* __restrict__ en_g, int64_t N, int K, int d, int Kc,
+    int32_t* __restrict__ idx_out, T* __restrict__ zq_out, float* __restrict__ partial /*[grid*NW]*/,
+    const typename DT<T>::frag_t* __restrict__ pk, VqCtl* __restrict__ ctl, int32_t* __restrict__ counts_out, float* __restrict__ stats_out) {
+  typedef typename DT<T>::frag_t frag_t;
+  constexpr int FE = DT<T>::FE;
+  constexpr int q = NF * FE;                 // channels per lane quarter
+  constexpr int BATCH = NW * NT * 16;        // rows per workgroup batch = capacity of the parked list
+  constexpr int CAND_CAP = NW * 64;          // one candidate per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  frag_t* wl = reinterpret_cast<frag_t*>(smem);                                               // [Kc/16][NF][64]
+  float* enl = reinterpret_cast<float*>(smem + (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t)); // [Kc] ||e||^2 (3e38 beyond K)
+  int* hist = reinterpret_cast<int*>(enl + Kc);                                               // [K]
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(hist + ((K + 1) & ~1));    // [VQ_FAST_ROWS] float64 bits of the minimum
+  int* bestk = reinterpret_cast<int*>(best + VQ_FAST_ROWS);                                   // [VQ_FAST_ROWS]
+  int* park = bestk + VQ_FAST_ROWS;                                                           // [BATCH] x {row - batch base, limit (f32 bits)}
+  int* cand = park + 2 * BATCH;                                                               // [CAND_CAP] (slot << 16) | code
+  int* misc = cand + CAND_CAP;                                                                // [0..NW) parked per wave, [16] candidates, [17] last flag, [18..18+NW) f32 maxima
+  int32_t* counts_acc = reinterpret_cast<int32_t*>(ctl + 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vx = lane & 15, kc = lane >> 4;
+  const bool fast = (d == 4 * q);
+  const int nmb = Kc / 16;
+#ifdef VQ_STAMPS
+  __shared__ unsigned long long vq_ts[16][8];
+  if (tid < 128) (&vq_ts[0][0])[tid] = 0ull;
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_begin = t_prev;
+  const unsigned long long w_begin = wall_clock64();               // constant 100 MHz counter: calibrates the s_memtime ticks
+#define VQ_ST(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); if (lane == 0) vq_ts[wave][i] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define VQ_ST(i) do { } while (0)
+#endif
+
+  // ---- the first batch's rows are requested before the codebook image so that both latencies overlap ----
+  const int64_t nbatch = (N + BATCH - 1) / BATCH;
+  LQTile<T, NF> zt[NT];
+  auto load_batch = [&](int64_t b, int tid_) {
+    const int64_t r0 = b * BATCH + (int64_t)(tid_ >> 6) * (NT * 16);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      int64_t row = r0 + t * 16 + (tid_ & 15);
+      if (row >= N) row = N - 1;
+      lq_load<T, NF>(zt[t], Z, row, d, (tid_ >> 4) & 3, fast);
     }
-    if (tid == 0 && n_resolved) atomicAdd(&hdr_w->namb, n_resolved);
-    // publish (partials by plain stores, counts by atomics), then take a ticket; the last workgroup folds everything
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int ticket = __hip_atomic_fetch_add(&hdr_w->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      amb_n[1] = (ticket == (int)gridDim.x - 1) ? 1 : 0;
-      if (ticket == (int)gridDim.x - 1) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  if ((int64_t)blockIdx.x < nbatch) load_batch(blockIdx.x, tid);
+  // ---- once per workgroup: codebook image, norms, their maximum, cleared histogram / lists ----
+  copy_frags_lds<T>(wl, pk, nmb * NF * 64, tid, NW * 64);
+  float enmax;
+  {
+    float m = 0.f;
+    for (int i = tid; i < Kc; i += NW * 64) {
+      const float v = i < K ? en_g[i] : 3.0e38f;
+      enl[i] = v;
+      if (i < K) m = fmaxf(m, v);
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) misc[18 + wave] = __float_as_int(m);
+  }
+  for (int k = tid; k < K; k += NW * 64) hist[k] = 0;
+  if (tid < VQ_FAST_ROWS) { best[tid] = ~0ull; bestk[tid] = 0x7fffffff; }
+  if (tid == 0) misc[16] = 0;
+  __syncthreads();
+  {
+    float m = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) m = fmaxf(m, __int_as_float(misc[18 + w]));
+    enmax = m;
+  }
+  const float err_rel = (float)(4 * q + 8) * 1.1920929e-7f;            // (d_pad+8) * 2^-23: f32 accumulation of exact products
+  const float thr_rel = (3.0517578125e-5f + 2.f * err_rel) * 1.001953125f;   // 2^-15: key truncation of both scores, + 2*err, + margin
+  const float enroot = sqrtf(enmax);
+  float sq_acc = 0.f;
+  int n_resolved = 0;
+  VQ_ST(2);
+
+  for (int64_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+    const int64_t base = batch * BATCH;
+    const int64_t v0 = base + (int64_t)wave * (NT * 16);
+    if (batch != (int64_t)blockIdx.x) {                            // (the first batch is already in flight)
+      int tidl = tid;
+      asm volatile("" : "+v"(tidl));                               // (no row addresses carried around the loop)
+      load_batch(batch, tidl);
+    }
+    float thr[NT];
+    unsigned g1[NT], g2[NT];
+    int gc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float zn = 0.f;
+#pragma unroll
+      for (int s = 0; s < NF; ++s)
+#pragma unroll
+        for (int e = 0; e < FE; ++e) { const float v = lq_get<T, NF>(zt[t], s, e); zn = fmaf(v, v, zn); }
+      zn += __shfl_xor(zn, 16, 64);
+      zn += __shfl_xor(zn, 32, 64);
+      const float sroot = sqrtf(zn) + enroot;                      // |score| and every partial sum <= (||z|| + ||e||max)^2
+      thr[t] = sroot * sroot * thr_rel + 1e-37f;
+#pragma unroll
+      for (int s = 0; s < NF; ++s) asm volatile("" : "+v"(zt[t].f[s]));   // (else the unpacked floats stay live through the main loop)
+      g1[t] = 0x7F800000u; g2[t] = 0x7F800000u; gc[t] = 0;         // +inf
+    }
+    VQ_ST(0);                                                      // z loads + norms (includes the load latency)
+    for (int g0 = 0; g0 < nmb; g0 += 8) {
+      unsigned c1[NT], c2[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { c1[t] = 0x7F800000u; c2[t] = 0x7F800000u; }
+      const int g1e = (g0 + 8) < nmb ? (g0 + 8) : nmb;
+      for (int mb = g0; mb < g1e; ++mb) {
+        const f32x4 en4 = *reinterpret_cast<const f32x4*>(enl + mb * 16 + 4 * kc);
+        frag_t a[NF];
+#pragma unroll
+        for (int s = 0; s < NF; ++s) a[s] = wl[(mb * NF + s) * 64 + lane];
+        const unsigned lidx = (unsigned)((mb - g0) * 16 + 4 * kc);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          f32x4 acc = en4;
+#pragma unroll
+          for (int s = 0; s < NF; ++s) acc = mfma16(a[s], zt[t].f[s], acc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned key = (__float_as_uint(acc[r]) & ~VQ_IDX_MASK) | (lidx + r);
+            asm("v_med3_f32 %0, %1, %2, %3" : "=v"(c2[t]) : "v"(c1[t]), "v"(c2[t]), "v"(key));   // runner-up (c1 <= c2)
+            asm("v_min_f32 %0, %1, %2" : "=v"(c1[t]) : "v"(c1[t]), "v"(key));
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {                               // fold the group of 128 codes into the running (best, runner-up, group)
+        const float a1 = __uint_as_float(g1[t]), a2 = __uint_as_float(g2[t]), b1 = __uint_as_float(c1[t]), b2 = __uint_as_float(c2[t]);
+        const float hi = fmaxf(a1, b1), lo2 = fminf(a2, b2);
+        g2[t] = __float_as_uint(fminf(hi, lo2));
+        if (b1 < a1) { g1[t] = c1[t]; gc[t] = g0; }
       }
     }
-    __syncthreads();
-    if (amb_n[1]) {
-      double* red = reinterpret_cast<double*>(smem);                // (the codebook fragments are no longer needed)
-      const int npartial = (int)gridDim.x * NW;
-      double sp = 0.0;
-      for (int i = tid; i < npartial; i += NW * 64) sp += (double)partial[i];
-      double hp = 0.0;
-      for (int k = tid; k < K; k += NW * 64) {
-        const int c = __hip_atomic_load(&counts_acc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        counts_out[k] = c;
-        const double p = (double)c / (double)N;
-        hp += p * log(p + 1e-10);
+    VQ_ST(3);                                                      // MFMA + key / min / med3 main loop
+    // ---- min-reduce over the 4 lane groups that share a row; ambiguity test; z_q, squared error, histogram of the settled rows ----
+    // (opaque copies of the lane coordinates: keeps the epilogue's address arithmetic out of the main loop's register budget)
+    int tide = tid;
+    asm volatile("" : "+v"(tide));
+    const int vxe = tide & 15, kce = (tide >> 4) & 3;
+    const int64_t v0e = base + (int64_t)(tide >> 6) * (NT * 16);
+    float lim[NT];
+    unsigned ambm = 0u;                                            // bit t: row (t, vxe) is parked (valid in the kce == 0 lanes)
+    int nparked = 0, rank[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int off = 16; off <= 32; off <<= 1) {
+        const unsigned o1 = __shfl_xor(g1[t], off, 64), o2 = __shfl_xor(g2[t], off, 64);
+        const int oc = __shfl_xor(gc[t], off, 64);
+        const float a1 = __uint_as_float(g1[t]), a2 = __uint_as_float(g2[t]), b1 = __uint_as_float(o1), b2 = __uint_as_float(o2);
+        const float hi = fmaxf(a1, b1), lo2 = fminf(a2, b2);
+        g2[t] = __float_as_uint(fminf(hi, lo2));
+        if (b1 < a1 || (b1 == a1 && (oc < gc[t] || (oc == gc[t] && o1 < g1[t])))) { g1[t] = o1; gc[t] = oc; }
       }
-      red[tid] = sp;
-      red[NW * 64 + tid] = hp;
+      const int64_t row = v0e + t * 16 + vxe;
+      const int code = gc[t] * 16 + (int)(g1[t] & VQ_IDX_MASK);
+      const float s1 = __uint_as_float(g1[t] & ~VQ_IDX_MASK), s2 = __uint_as_float(g2[t] & ~VQ_IDX_MASK);
+      const bool amb = !((s2 - s1) > thr[t]) || (unsigned)code >= (unsigned)K;   // also catches NaN / inf rows
+      lim[t] = s1 + thr[t] + 2.3841858e-7f * fabsf(s1);
+      const unsigned long long pm = __builtin_amdgcn_ballot_w64(amb && kce == 0 && row < N);
+      rank[t] = nparked + __builtin_popcountll(pm & ((1ull << vxe) - 1ull));
+      nparked += __builtin_popcountll(pm);
+      if (amb) ambm |= 1u << t;
+      if (row < N && !amb) {
+        T* zo = zq_out + row * (int64_t)d + q * kce;
+        if (fast) {
+          if constexpr (FE == 8) {                                 // e (rounded to bf16) = -0.5 * the packed -2e: exact
+#pragma unroll
+            for (int s = 0; s < NF; ++s) {
+              const bf16x8 pv = wl[((code >> 4) * NF + s) * 64 + (code & 15) + 16 * kce];
+              bf16x8 ev;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float f = -0.5f * (float)pv[e];
+                ev[e] = (bf16)f;
+                const float df = (float)zt[t].f[s][e] - f;
+                sq_acc = fmaf(df, df, sq_acc);
+              }
+              *reinterpret_cast<bf16x8*>(zo + 8 * s) = ev;
+            }
+          } else {
+            const float* er = E + (int64_t)code * d + q * kce;
+#pragma unroll
+            for (int s = 0; s < NF * FE; s += DT<T>::VEC) {
+              float ev[DT<T>::VEC];
+#pragma unroll
+              for (int e = 0; e < DT<T>::VEC; ++e) ev[e] = to_f32(from_f32<T>(er[s + e]));
+              Vec<T>::store(zo + s, ev);
+#pragma unroll
+              for (int e = 0; e < DT<T>::VEC; ++e) {
+                const float df = lq_get<T, NF>(zt[t], (s + e) / FE, (s + e) % FE) - ev[e];
+                sq_acc = fmaf(df, df, sq_acc);
+              }
+            }
+          }
+        } else {
+          const float* er = E + (int64_t)code * d + q * kce;
+#pragma unroll
+          for (int s = 0; s < NF * FE; ++s) {
+            if (q * kce + s < d) {
+              const float ev = to_f32(from_f32<T>(er[s]));
+              zo[s] = from_f32<T>(ev);
+              const float df = lq_get<T, NF>(zt[t], s / FE, s % FE) - ev;
+              sq_acc = fmaf(df, df, sq_acc);
+            }
+          }
+        }
+        if (kce == 0) { idx_out[row] = code; atomicAdd(&hist[code], 1); }
+      }
+    }
+    VQ_ST(4);                                                      // reduce, ambiguity test, z_q, histogram
+    // ---- park the ambiguous rows in row order: slot = (rows parked by the waves before this one) + rank inside the wave ----
+    if ((tide & 63) == 0) misc[tide >> 6] = nparked;
+    __syncthreads();
+    int pbase = 0, n = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const int c = misc[w]; if (w < (tide >> 6)) pbase += c; n += c; }
+    if (n == 0) { __syncthreads(); continue; }                     // (uniform) nothing to resolve in this batch
+    if (kce == 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (((ambm >> t) & 1u) && v0e + t * 16 + vxe < N) {
+          park[2 * (pbase + rank[t])] = (tide >> 6) * (NT * 16) + t * 16 + vxe;
+          park[2 * (pbase + rank[t]) + 1] = __float_as_int(lim[t]);
+        }
+    }
+    __syncthreads();
+    bool all_waves = n <= VQ_FAST_ROWS;
+    int tidr = tid;
+    asm volatile("" : "+v"(tidr));
+    if (all_waves) {
+      // ---- screen: wave w re-scores every tile of 16 parked rows against its share of the code blocks ----
+      const int waver = tidr >> 6, laner = tidr & 63, vxr = tidr & 15, kcr = (tidr >> 4) & 3;
+      const int mb0 = (waver * nmb) / NW, mb1 = ((waver + 1) * nmb) / NW;
+      for (int t0 = 0; t0 < n; t0 += 16) {
+        const int li = t0 + vxr;
+        const bool valid = li < n;
+        const int64_t row = base + park[2 * (valid ? li : t0)];
+        const float lm = __int_as_float(park[2 * (valid ? li : t0) + 1]);
+        LQTile<T, NF> zr;
+        lq_load<T, NF>(zr, Z, row, d, kcr, fast);
+        for (int mb = mb0; mb < mb1; ++mb) {
+          f32x4 acc = *reinterpret_cast<const f32x4*>(enl + mb * 16 + 4 * kcr);
+#pragma unroll
+          for (int s = 0; s < NF; ++s) acc = mfma16(wl[(mb * NF + s) * 64 + laner], zr.f[s], acc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int code = mb * 16 + 4 * kcr + r;
+            if (valid && acc[r] <= lm && code < K) {
+              const int pos = atomicAdd(&misc[16], 1);
+              if (pos < CAND_CAP) cand[pos] = (li << 16) | code;
+            }
+          }
+        }
+      }
       __syncthreads();
-      for (int o = NW * 32; o > 0; o >>= 1) {
-        if (tid < o) { red[tid] += red[tid + o]; red[NW * 64 + tid] += red[NW * 64 + tid + o]; }
+      const int ncand = misc[16];
+      all_waves = ncand <= CAND_CAP;                               // (uniform)
+      if (all_waves) {
+        // ---- one lane per candidate: float64 distance; minimum per row, then the smallest code among the minima ----
+        const int c = laner * NW + waver;                            // spread the few candidates over the waves
+        int li = 0, code = 0;
+        unsigned long long bits = ~0ull;
+        if (c < ncand) {
+          const int cv = cand[c];
+          li = cv >> 16; code = cv & 0xffff;
+          const double dist = vq_exact_one<T>(Z, E, base + park[2 * li], code, d);
+          bits = (unsigned long long)__double_as_longlong(dist);
+          __hip_atomic_fetch_min(&best[li], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         __syncthreads();
+        if (c < ncand && bits == best[li]) __hip_atomic_fetch_min(&bestk[li], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        // ---- outputs of the resolved rows: 16 lanes per row ----
+        const int j = tidr & 15;
+        for (int li2 = tidr >> 4; li2 < n; li2 += NW * 4) {
+          int bk = bestk[li2];
+          if ((unsigned)bk >= (unsigned)K) bk = 0;                 // no candidate at all (NaN row): argmin of an all-NaN row is 0
+          const int64_t row = base + park[2 * li2];
+          for (int ch = j; ch < d; ch += 16) {
+            const float ev = to_f32(from_f32<T>(E[(int64_t)bk * d + ch]));
+            zq_out[row * (int64_t)d + ch] = from_f32<T>(ev);
+            const float df = to_f32(Z[row * (int64_t)d + ch]) - ev;
+            sq_acc = fmaf(df, df, sq_acc);
+          }
+          if (j == 0) { idx_out[row] = bk; atomicAdd(&hist[bk], 1); }
+        }
+        __syncthreads();
+        if (tidr < VQ_FAST_ROWS && tidr < n) {
+          int m1 = -1;
+          asm volatile("" : "+v"(m1));                              // (materialised here, not carried through the batch loop)
+          best[tidr] = ((unsigned long long)(unsigned)m1 << 32) | (unsigned)m1;
+          bestk[tidr] = 0x7fffffff;
+        }
       }
-      if (tid == 0) {
-        stats_out[0] = (float)red[0];
-        stats_out[1] = (float)exp(-red[NW * 64]);
-        stats_out[2] = (float)__hip_atomic_load(&hdr_w->namb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        stats_out[3] = 0.f;
+    }
+    if (!all_waves) {
+      // ---- many parked rows / candidates (constructed inputs): one wave per tile of 16 parked rows, candidates evaluated in-lane
+      // (up to two pending per lane, flushed together); same float64 arithmetic as above ----
+      for (int t0 = wave * 16; t0 < n; t0 += NW * 16) {
+        const int li = t0 + vx;
+        const bool valid = li < n;
+        const int64_t row = base + park[2 * (valid ? li : t0)];
+        const float lm = __int_as_float(park[2 * (valid ? li : t0) + 1]);
+        LQTile<T, NF> zr;
+        lq_load<T, NF>(zr, Z, row, d, kc, fast);
+        double bestd = 1.0e300;
+        int bk = 0x7fffffff, p0 = -1, p1 = -1;
+        auto flush = [&]() {
+          if (p0 >= 0) {
+            double d0, d1;
+            vq_exact_pair<T, 1>(Z, E, row, p0, p1, d, d0, d1);
+            if (d0 < bestd || (d0 == bestd && p0 < bk)) { bestd = d0; bk = p0; }
+            if (p1 >= 0 && (d1 < bestd || (d1 == bestd && p1 < bk))) { bestd = d1; bk = p1; }
+          }
+          p0 = p1 = -1;
+        };
+#pragma unroll 4
+        for (int mb = 0; mb < nmb; ++mb) {
+          f32x4 acc = *reinterpret_cast<const f32x4*>(enl + mb * 16 + 4 * kc);
+#pragma unroll
+          for (int s = 0; s < NF; ++s) acc = mfma16(wl[(mb * NF + s) * 64 + lane], zr.f[s], acc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int code = mb * 16 + 4 * kc + r;
+            const bool hit = acc[r] <= lm && code < K;
+            if (__builtin_amdgcn_ballot_w64(hit && p1 >= 0) != 0ull) flush();       // a lane with both slots taken: evaluate all pending
+            if (hit) { if (p0 < 0) p0 = code; else p1 = code; }
+          }
+        }
+        flush();
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+          const double ob = __shfl_xor(bestd, off, 64);
+          const int okk = __shfl_xor(bk, off, 64);
+          if (ob < bestd || (ob == bestd && okk < bk)) { bestd = ob; bk = okk; }
+        }
+        if ((unsigned)bk >= (unsigned)K) bk = 0;
+        if (valid) {
+          const float* er = E + (int64_t)bk * d + q * kc;
+          T* zo = zq_out + row * (int64_t)d + q * kc;
+#pragma unroll
+          for (int s = 0; s < NF * FE; ++s) {
+            if (q * kc + s < d) {
+              const float ev = to_f32(from_f32<T>(er[s]));
+              zo[s] = from_f32<T>(ev);
+              const float df = lq_get<T, NF>(zr, s / FE, s % FE) - ev;
+              sq_acc = fmaf(df, df, sq_acc);
+            }
+          }
+          if (kc == 0) { idx_out[row] = bk; atomicAdd(&hist[bk], 1); }
+        }
       }
+    }
+    n_resolved += n;
+    __syncthreads();
+    if (tid == 0) misc[16] = 0;
+    VQ_ST(5);                                                      // exact re-evaluation of the parked rows
+  }
+  // ---- per-workgroup outputs: wave partials of the squared error; histogram by integer atomics (order-independent) ----
+  int tidt = tid;                                                   // (opaque: the tail's addresses are computed here, not kept in registers / scratch from the prologue on)
+  asm volatile("" : "+v"(tidt));
+  const float ws_ = wave_sum(sq_acc);
+  if ((tidt & 63) == 0) partial[blockIdx.x * NW + (tidt >> 6)] = ws_;
+  __syncthreads();
+  for (int k = tidt; k < K; k += NW * 64) {
+    const int h = hist[k];
+    if (h) atomicAdd(&counts_acc[k], h);
+  }
+  if (tidt == 0 && n_resolved) atomicAdd(&ctl->namb, n_resolved);
+  // publish (partials by plain stores, counts by atomics), then take a ticket; the last workgroup folds everything
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tidt == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ticket = __hip_atomic_fetch_add(&ctl->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    misc[17] = (ticket == (int)gridDim.x - 1) ? 1 : 0;
+    if (ticket == (int)gridDim.x - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  const bool last = misc[17] != 0;
+  __syncthreads();                                                  // (red below may overlap misc when the image is tiny)
+  if (last) {
+    double* red = reinterpret_cast<double*>(smem);                  // (the codebook fragments are no longer needed)
+    const int npartial = (int)gridDim.x * NW;
+    double sp = 0.0;
+    for (int i = tidt; i < npartial; i += NW * 64) sp += (double)__hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double hp = 0.0;
+    for (int k = tidt; k < K; k += NW * 64) {
+      const int c = __hip_atomic_load(&counts_acc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      counts_out[k] = c;
+      __hip_atomic_store(&counts_acc[k], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // clean for the next call
+      const double p = (double)c / (double)N;
+      hp += p * log(p + 1e-10);
+    }
+    sp = wave_sum_d(sp);
+    hp = wave_sum_d(hp);
+    if ((tidt & 63) == 0) { red[tidt >> 6] = sp; red[NW + (tidt >> 6)] = hp; }
+    __syncthreads();
+    if (tidt == 0) {
+      for (int w = 1; w < NW; ++w) { red[0] += red[w]; red[NW] += red[NW + w]; }     // fixed order
+    }
+    if (tidt == 0) {
+      stats_out[0] = (float)red[0];
+      stats_out[1] = (float)exp(-red[NW]);
+      stats_out[2] = (float)__hip_atomic_load(&ctl->namb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      stats_out[3] = 0.f;
+      __hip_atomic_store(&ctl->namb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ctl->done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 #ifdef VQ_STAMPS
-  VQ_ST(6);                                                      // partials, histogram atomics, ticket, (last workgroup) statistics
+  VQ_ST(6);                                                        // partials, histogram atomics, ticket, (last workgroup) statistics
   __syncthreads();
   if (tid < 128) vq_dbg[(size_t)blockIdx.x * 128 + tid] = (&vq_ts[0][0])[tid];
+  if (tid == 0) { vq_dbg[(size_t)gridDim.x * 128 + 2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_begin; vq_dbg[(size_t)gridDim.x * 128 + 2 * blockIdx.x + 1] = wall_clock64() - w_begin; }
 #endif
 }
 
@@ -1008,7 +1292,7 @@ static int vq_grid(int64_t N, int d) {
 #define VQ_BWD_WGS 256
 
 // "prepared codebook": [||e||^2: kpad floats (3e38 beyond K)][packed -2e fragments of kpad codes]; kpad = K rounded up to whole chunks
-struct VqPrep { size_t en, pack, total; int Kc, kpad, npk; };
+struct VqPrep { size_t ctl, en, pack, total; int Kc, kpad, npk; };
 template <typename T, int NF>
 static VqPrep vq_prep_layout(int64_t N, int K, int d) {
   VqPrep P;
@@ -1016,12 +1300,16 @@ static VqPrep vq_prep_layout(int64_t N, int K, int d) {
   P.Kc = vq_chunk(K, d_pad, sizeof(T), vq_waves(N, d));
   P.kpad = (K + P.Kc - 1) / P.Kc * P.Kc;
   P.npk = (P.kpad / 16) * NF * 64;
-  P.en = 0;
-  P.pack = ((size_t)P.kpad * 4 + 255) / 256 * 256;
+  P.ctl = 0;                                                        // VqCtl + counts_acc[K] (kpad >= 64 always holds the 64 header ints)
+  P.en = (sizeof(VqCtl) + (size_t)K * 4 + 255) / 256 * 256;
+  P.pack = P.en + ((size_t)P.kpad * 4 + 255) / 256 * 256;
   P.total = P.pack + (size_t)P.npk * sizeof(typename DT<T>::frag_t);
   return P;
 }
-static size_t vq_prep_bytes_max(int K) { return ((size_t)(K + VQ_MAX_CHUNK) * 4 + 255) / 256 * 256 + (size_t)((K + 15) / 16 + 64) * 16 * 128 * 4; }
+static size_t vq_prep_bytes_max(int K) {
+  return (sizeof(VqCtl) + (size_t)K * 4 + 255) / 256 * 256 + ((size_t)(K + VQ_MAX_CHUNK) * 4 + 255) / 256 * 256 +
+         (size_t)((K + 15) / 16 + 64) * 16 * 128 * 4;
+}
 
 struct VqLayout { size_t hdr, counts_fix, partial, amb, hist, prep, total; int grid; };
 static VqLayout vq_layout(int64_t N, int K, int d) {
@@ -1043,13 +1331,14 @@ static int launch_vq_prepare(const float* E, int64_t N, int K, int d, char* prep
   typedef typename DT<T>::frag_t frag_t;
   const VqPrep P = vq_prep_layout<T, NF>(N, K, d);
   const int npack_blocks = (P.npk + 255) / 256;
-  FRL_LAUNCH((vq_prepare_kernel<T, NF>), dim3(npack_blocks + (P.kpad + 255) / 256), dim3(256), 0, st, E, K, d, (float*)(prep + P.en), P.kpad,
-             (frag_t*)(prep + P.pack), P.npk, npack_blocks);
+  const int kz = P.kpad > 64 ? P.kpad : 64;                         // the norms blocks also zero the 64 header ints of the control block
+  FRL_LAUNCH((vq_prepare_kernel<T, NF>), dim3(npack_blocks + (kz + 255) / 256), dim3(256), 0, st, E, K, d, (float*)(prep + P.en), P.kpad,
+             (frag_t*)(prep + P.pack), P.npk, npack_blocks, (int*)(prep + P.ctl));
   return frl_check_launch("vq_prepare");
 }
 
 template <typename T, int NF>
-static int launch_vq(const void* z, const float* E, const char* prep, int64_t N, int K, int d, int32_t* idx, void* zq, float* stats,
+static int launch_vq(const void* z, const float* E, char* prep, int64_t N, int K, int d, int32_t* idx, void* zq, float* stats,
                      int32_t* counts, char* ws, hipStream_t st) {
   typedef typename DT<T>::frag_t frag_t;
   const VqLayout L = vq_layout(N, K, d);
@@ -1057,7 +1346,8 @@ static int launch_vq(const void* z, const float* E, const char* prep, int64_t N,
   const int nw = vq_waves(N, d);
   const int Kc = P.Kc;
   VqHeader* hdr = (VqHeader*)(ws + L.hdr);
-  FRL_HIP(hipMemsetAsync(ws, 0, L.partial, st));                     // header + counts_fix (= counts_acc of the fused path)
+  const bool resident = P.kpad == Kc;                                // the whole codebook is one LDS chunk
+  if (!resident) FRL_HIP(hipMemsetAsync(ws, 0, L.partial, st));      // header + counts_fix of the multi-chunk path
   if (prep == nullptr) {                                             // one-call entry point: prepare into the workspace first
     const int rc = launch_vq_prepare<T, NF>(E, N, K, d, ws + L.prep, st);
     if (rc) return rc;
@@ -1065,22 +1355,43 @@ static int launch_vq(const void* z, const float* E, const char* prep, int64_t N,
   }
   const float* en = (const float*)(prep + P.en);
   const frag_t* pk = (const frag_t*)(prep + P.pack);
-  const bool fused = P.kpad == Kc;                                   // the whole codebook is one LDS chunk
-  size_t lds = (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc * 4 + (size_t)K * 4 + 128;
-  if (fused) lds += (size_t)Kc * 4 + (size_t)3 * VQ_AMB_CAP * 4 + 16;
-  if (lds > 160 * 1024) return frl_fail(-3, "vq_assign: LDS budget exceeded (K too large for histogram)");
-#define VQ_GO(NT_, NW_, FUSED_)                                                                                                    \
+  if (resident) {
+    // image | norms | histogram | per-row minima | parked rows | candidates | misc; the statistics fold of the last workgroup reuses the front
+    const int nwr = (nw == 8 && NF <= (sizeof(T) == 2 ? 2 : 4)) ? 8 : 4;  // 8 waves x 4 tiles only where the tiles fit the 128-register budget
+    const int batch = nwr * 4 * 16;
+    const int64_t nb = (N + batch - 1) / batch;
+    const int grid_r = (int)(nb < L.grid ? nb : L.grid);
+    size_t lds = (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc * 4 + (size_t)((K + 1) & ~1) * 4 + (size_t)VQ_FAST_ROWS * 12 +
+                 (size_t)2 * batch * 4 + (size_t)nwr * 64 * 4 + 32 * 4;
+    const size_t fold = (size_t)2 * nwr * 64 * sizeof(double);
+    if (lds < fold) lds = fold;
+    if (lds > 160 * 1024) return frl_fail(-3, "vq_assign: LDS budget exceeded");
+#define VQ_GO(NW_)                                                                                                                 \
   do {                                                                                                                             \
-    auto kern = vq_assign_kernel<T, NF, NT_, NW_, FUSED_>;                                                                         \
+    auto kern = vq_assign_resident_kernel<T, NF, 4, NW_>;                                                                          \
     if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
-    FRL_LAUNCH_AS("vq_assign_kernel", kern, dim3(L.grid), dim3(64 * NW_), lds, st, (const T*)z, E, en, hdr, N, K, d, Kc, idx, (T*)zq,     \
-                  (float*)(ws + L.partial), (int32_t*)(ws + L.hist), hdr, (int32_t*)(ws + L.amb), pk, (int32_t*)(ws + L.counts_fix), \
-                  counts, stats);                                                                                                  \
+    FRL_LAUNCH_AS("vq_assign_kernel", kern, dim3(grid_r), dim3(64 * NW_), lds, st, (const T*)z, E, en, N, K, d, Kc, idx, (T*)zq,   \
+                  (float*)(ws + L.partial), pk, (VqCtl*)(prep + P.ctl), counts, stats);                                            \
   } while (0)
-  if (nw == 8) { if (fused) VQ_GO(2, 8, true); else VQ_GO(2, 8, false); }
-  else { if (fused) VQ_GO(4, 4, true); else VQ_GO(4, 4, false); }
+    if constexpr (NF <= (sizeof(T) == 2 ? 2 : 4)) {
+      if (nwr == 8) VQ_GO(8); else VQ_GO(4);
+    } else {
+      VQ_GO(4);
+    }
 #undef VQ_GO
-  if (fused) return frl_check_launch("vq_assign");
+    return frl_check_launch("vq_assign");
+  }
+  size_t lds = (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc * 4 + (size_t)K * 4 + 128;
+  if (lds > 160 * 1024) return frl_fail(-3, "vq_assign: LDS budget exceeded (K too large for histogram)");
+#define VQ_GO(NT_, NW_)                                                                                                            \
+  do {                                                                                                                             \
+    auto kern = vq_assign_kernel<T, NF, NT_, NW_>;                                                                                 \
+    if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+    FRL_LAUNCH_AS("vq_assign_kernel", kern, dim3(L.grid), dim3(64 * NW_), lds, st, (const T*)z, E, en, hdr, N, K, d, Kc, idx, (T*)zq, \
+                  (float*)(ws + L.partial), (int32_t*)(ws + L.hist), hdr, (int32_t*)(ws + L.amb), pk);                             \
+  } while (0)
+  if (nw == 8) VQ_GO(2, 8); else VQ_GO(4, 4);
+#undef VQ_GO
   const size_t fix_lds = (size_t)4 * (d + 64 * (d + 1)) * sizeof(float);
   {
     auto fk = vq_fixup_kernel<T>;
@@ -1178,13 +1489,14 @@ int frl_vq_prepare(const float* E, int64_t N, int K, int d, int dtype, void* pre
 // z [N][d] (dtype), E [K][d] f32 master codebook.  Outputs: idx_out [N] int32, zq_out [N][d] (dtype, the
 // codebook rows rounded to dtype), stats_out [4] f32 = {sum ||z - z_q||^2, perplexity, #rows re-evaluated in
 // float64, 0}, counts_out [K] int32 code usage.  In bf16 mode distances are taken to the bf16-rounded codebook.
-// prep: NULL, or the image frl_vq_prepare wrote for THIS codebook content, dtype and row count class.
-int frl_vq_assign_fwd_prepared(const void* z, const float* E, const void* prep, int64_t N, int K, int d, int32_t* idx_out, void* zq_out,
+// prep: NULL, or the image frl_vq_prepare wrote for THIS codebook content, dtype and row count class.  The image carries the kernel's
+// arrival counter and histogram accumulator (zeroed by frl_vq_prepare, left zeroed by every call): one call in flight per image.
+int frl_vq_assign_fwd_prepared(const void* z, const float* E, void* prep, int64_t N, int K, int d, int32_t* idx_out, void* zq_out,
                                float* stats_out, int32_t* counts_out, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (N <= 0 || K <= 0 || d <= 0) return frl_fail(-2, "vq_assign: empty input");
   if (d > 128) return frl_fail(-2, "vq_assign: d > 128 unsupported");
   if (ws_bytes < frl_vq_workspace_bytes(N, K, d)) return frl_fail(-4, "vq_assign: workspace too small");
-#define VQ_CALL_FWD(T_, NF_) launch_vq<T_, NF_>(z, E, (const char*)prep, N, K, d, idx_out, zq_out, stats_out, counts_out, (char*)ws, stream)
+#define VQ_CALL_FWD(T_, NF_) launch_vq<T_, NF_>(z, E, (char*)prep, N, K, d, idx_out, zq_out, stats_out, counts_out, (char*)ws, stream)
   VQ_DISPATCH(dtype, d, VQ_CALL_FWD);
 #undef VQ_CALL_FWD
 }
