@@ -64,6 +64,9 @@ int frl_conv1x1_fwd(const void* x, const float* w, const float* bias, void* y, i
                     int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
 int frl_conv1x1_bwd_data(const void* dy, const void* y, int act, const float* w, void* dx, int64_t P, int Cin, int Cout,
                          int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
+/* Tuning hook (no reference counterpart): upper bound of the workgroups, i.e. float32 partial slabs, of a 1x1 weight-gradient launch;
+ * returns the previous bound.  frl_conv1x1_bwd_weight_workspace_bytes follows it: size workspaces after changing it. */
+int frl_wgrad_set_max_workgroups(int n);
 size_t frl_conv1x1_bwd_weight_workspace_bytes(int64_t P, int Cin, int Cout);
 int frl_conv1x1_bwd_weight(const void* dy, const void* y, int act, const void* x, float* dw, float* dbias, int64_t P,
                            int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
@@ -84,6 +87,9 @@ int frl_conv3x3_bwd_data(const void* dy, const void* y, int act, const float* w,
 size_t frl_conv3x3_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int frl_conv3x3_bwd_weight(const void* dy, const void* y, int act, const void* x, float* dw, float* dbias, int B, int H,
                            int W, int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, int flags, frl_stream_t stream);
+/* Test / A-B hook (no reference counterpart): 1 routes every 3x3 weight gradient through the generic kernel instead of the bf16
+ * band kernel; returns the previous setting. */
+int frl_conv3x3_wgrad_force_generic(int on);
 
 /* ---- GroupNorm over NHWC rows ----------------------------------------------------------------------------------
  * nn.GroupNorm(G, C), eps 1e-5, per-sample statistics: frl/models/conv2d_encoder.py:117 (ReLU fused when relu=1,

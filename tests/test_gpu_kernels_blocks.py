@@ -50,7 +50,10 @@ def test_groupnorm(dtype, atol, wtol, B, HW, C, G, relu):
 
 @pytest.mark.parametrize("dtype,atol,wtol", MODES)
 @pytest.mark.parametrize("B,H,W,cin,cout,act", [(2, 32, 32, 128, 64, 1), (1, 8, 8, 16, 8, 1), (2, 8, 8, 8, 8, 2), (1, 13, 21, 64, 64, 0),
-                                                (1, 16, 16, 64, 128, 2)])
+                                                (1, 16, 16, 64, 128, 2),
+                                                # bf16 band kernel of the weight gradient: bands side by side (W = 64), two output slices,
+                                                # no mask, and more bands than workgroups (two per workgroup, idle workgroups write zeros)
+                                                (3, 16, 64, 64, 128, 2), (1, 8, 32, 64, 64, 0), (70, 32, 32, 64, 64, 1)])
 def test_conv3x3(dtype, atol, wtol, B, H, W, cin, cout, act):
     from frl_hip import ops
     g = torch.Generator().manual_seed(H * W + cin + cout)

@@ -552,6 +552,11 @@ static int c3_wgrad_nwg(int B, int H, int W) {
   const int tiles = B * ((H + C3W_TH - 1) / C3W_TH) * ((W + C3_TW - 1) / C3_TW);
   return tiles < 256 ? tiles : 256;
 }
+// bf16 band kernel (conv3x3_wgrad.hip): 8 x 32-pixel bands, LDS-DMA halo, same slab layout
+bool c3v_supported(int B, int H, int W, int Cin, int Cout, int dtype);
+int c3v_workgroups(int B, int H, int W);
+int c3v_launch(const void* dy, const void* ym, int act, const void* x, float* ws, int B, int H, int W, int Cin, int Cout, int oc_base,
+               hipStream_t st);
 
 extern "C" {
 
@@ -570,20 +575,26 @@ int frl_conv3x3_bwd_data(const void* dy, const void* y, int act, const float* w,
 
 size_t frl_conv3x3_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
   (void)Cout;
-  return (size_t)c3_wgrad_nwg(B, H, W) * ((size_t)64 * Cin * 9 + 64) * sizeof(float);
+  int nwg = c3_wgrad_nwg(B, H, W);
+  if (H % 8 == 0 && W % 32 == 0 && c3v_workgroups(B, H, W) > nwg) nwg = c3v_workgroups(B, H, W);
+  return (size_t)nwg * ((size_t)64 * Cin * 9 + 64) * sizeof(float);
 }
 
 // dw [Cout][Cin][3][3], dbias [Cout] (may be null).  flags bit0: scalar LDS fragment reads (debug A/B check)
 int frl_conv3x3_bwd_weight(const void* dy, const void* y, int act, const void* x, float* dw, float* dbias, int B, int H, int W,
                            int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, int flags, hipStream_t stream) {
   if (ws_bytes < frl_conv3x3_bwd_weight_workspace_bytes(B, H, W, Cin, Cout)) return frl_fail(-4, "conv3x3_bwd_weight: workspace too small");
-  const int nwg = c3_wgrad_nwg(B, H, W);
+  const bool band = c3v_supported(B, H, W, Cin, Cout, dtype) && (flags & 1) == 0;
+  const int nwg = band ? c3v_workgroups(B, H, W) : c3_wgrad_nwg(B, H, W);
   const int tiles = B * ((H + C3W_TH - 1) / C3W_TH) * ((W + C3_TW - 1) / C3_TW);
   const int tpw = (tiles + nwg - 1) / nwg;
   const void* ym = act != FRL_ACT_NONE ? y : nullptr;
   const int64_t slab_n = (int64_t)64 * Cin * 9 + 64;
   for (int oc_base = 0; oc_base < Cout; oc_base += 64) {
-    if (dtype == FRL_F32) {
+    if (band) {
+      const int rc = c3v_launch(dy, ym, act, x, (float*)ws, B, H, W, Cin, Cout, oc_base, stream);
+      if (rc) return rc;
+    } else if (dtype == FRL_F32) {
       const size_t lds = ((size_t)256 * (64 + 4) + (size_t)18 * 18 * (32 + 4)) * 4;
       auto kern = conv3x3_wgrad_kernel<float, 2, 1, 8>;
       FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -44,8 +44,14 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(
   const int64_t p_begin = (int64_t)blockIdx.x * rows_per_wg;
   int64_t p_end = p_begin + rows_per_wg;
   if (p_end > P) p_end = P;
-  const bool fastA = (Cout % VEC) == 0 && (ldy % VEC) == 0, fastB = (Cin % VEC) == 0;
+  // flatA: rows of dY are shorter than a 16-byte vector multiple (the 12-channel heads) but contiguous: a whole 64-row tile is copied
+  // as ONE flat run of 16-byte vectors and stays flat in LDS (row pitch = Cout; the 8-byte transposing reads only need Cout % 4 == 0;
+  // the columns a fragment reads beyond Cout belong to output channels that are never written)
+  const bool flatA = sizeof(T) == 2 && (Cout % VEC) != 0 && (Cout % 4) == 0 && ldy == Cout && (P % WG_KP) == 0;
+  const bool fastA = ((Cout % VEC) == 0 && (ldy % VEC) == 0) || flatA, fastB = (Cin % VEC) == 0;
   const bool fast = fastA && fastB;                          // 16-byte channel vectors: tiles are prefetched into registers
+  const int pA = flatA ? Cout : pitchA;                      // row pitch of the staged dY tile (elements)
+  const int nvA = flatA ? WG_KP * Cout / VEC : WG_KP * VPRA; // 16-byte vectors of the dY tile
   const int64_t shift = (int64_t)toff * HW;
 
   // register images of the next tile (fast path): raw dY / mask / X vectors, fetched behind the MFMAs of the current tile
@@ -56,8 +62,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(
       const int i = tid + u * 256;
       const int row = i / VPRA, c0 = (i % VPRA) * VEC;
       const int64_t p = p0 + row;
-      const bool ok = i < WG_KP * VPRA && p < p_end && c0 < Cout;
-      const int64_t off = ok ? p * ldy + c0 : 0;
+      const bool ok = flatA ? i < nvA : (i < WG_KP * VPRA && p < p_end && c0 < Cout);
+      const int64_t off = ok ? (flatA ? p0 * (int64_t)Cout + (int64_t)i * VEC : p * ldy + c0) : 0;
       vec_t v = *reinterpret_cast<const vec_t*>(dY + off);
       if (!ok) v = vec_t{};
       ra[u] = v;
@@ -83,14 +89,14 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
       const int i = tid + u * 256;
-      if (i >= WG_KP * VPRA) continue;
+      if (i >= nvA) continue;
       const int row = i / VPRA, c0 = (i % VPRA) * VEC;
       vec_t v = ra[u];
       if (Ymask != nullptr) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) v[e] = from_f32<T>(to_f32(v[e]) * act_bwd_from_y(to_f32(rm[u][e]), mask_act));
       }
-      *reinterpret_cast<vec_t*>(ldsA + row * pitchA + c0) = v;
+      *reinterpret_cast<vec_t*>(ldsA + (flatA ? i * VEC : row * pitchA + c0)) = v;
     }
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
@@ -176,15 +182,15 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(
           const int ch0 = (wave * OBW + o) * 16;
           bf16x8 af;
           if (use_tr) {
-            const T* a0 = ldsA + (pix0 + (r16 >> 2)) * pitchA + ch0 + 4 * (r16 & 3);
+            const T* a0 = ldsA + (pix0 + (r16 >> 2)) * pA + ch0 + 4 * (r16 & 3);
             bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                 (bf16x4 __attribute__((address_space(3)))*)(a0));
             bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                (bf16x4 __attribute__((address_space(3)))*)(a0 + 4 * pitchA));
+                (bf16x4 __attribute__((address_space(3)))*)(a0 + 4 * pA));
             af = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) af[j] = ldsA[(pix0 + j) * pitchA + ch0 + r16];
+            for (int j = 0; j < 8; ++j) af[j] = ldsA[(pix0 + j) * pA + ch0 + r16];
           }
 #pragma unroll
           for (int i = 0; i < IB; ++i) acc[o][i] = mfma16(af, bf[i], acc[o][i]);
@@ -246,9 +252,10 @@ struct WgradEpi {
   }
 };
 
+static int g_wgrad_max_wgs = 512;     // A/B at BASELINE configs[1] (tools/wgrad_bench.py): 512 beats 1024 (slab traffic) and 256 (latency hiding)
 static int wgrad_nwg(int64_t P) {
   int64_t n = (P + WG_KP - 1) / WG_KP;
-  if (n > 1024) n = 1024;
+  if (n > g_wgrad_max_wgs) n = g_wgrad_max_wgs;
   if (n < 1) n = 1;
   return (int)n;
 }
@@ -295,6 +302,14 @@ static int dispatch_wgrad(const void* dy, const void* ymask, int mask_act, const
 }
 
 extern "C" {
+
+// Tuning hook: upper bound of the workgroups (= float32 slabs to reduce) a weight-gradient launch uses; returns the previous bound.
+// Workspaces must be sized after the call (frl_conv1x1_bwd_weight_workspace_bytes follows the bound).
+int frl_wgrad_set_max_workgroups(int n) {
+  const int was = g_wgrad_max_wgs;
+  if (n >= 64 && n <= 4096) g_wgrad_max_wgs = n;
+  return was;
+}
 
 size_t frl_conv1x1_bwd_weight_workspace_bytes(int64_t P, int Cin, int Cout) {
   return (size_t)wgrad_nwg(P) * ((size_t)Cout * Cin + Cout) * sizeof(float);

@@ -39,6 +39,8 @@ SIGNATURES = {
     "frl_conv_workspace_bytes": (S, [I, I, I]),
     "frl_conv1x1_fwd": (c_int, [P, P, P, P, L, I, I, I, I, P, S, P]),
     "frl_conv1x1_bwd_data": (c_int, [P, P, I, P, P, L, I, I, I, P, S, P]),
+    "frl_wgrad_set_max_workgroups": (c_int, [I]),
+    "frl_conv3x3_wgrad_force_generic": (c_int, [I]),
     "frl_conv1x1_bwd_weight_workspace_bytes": (S, [L, I, I]),
     "frl_conv1x1_bwd_weight": (c_int, [P, P, I, P, P, P, L, I, I, I, P, S, P]),
     "frl_conv_tap_bwd_weight": (c_int, [P, P, I, P, P, L, L, P, L, I, I, I, I, I, I, P, S, I, P]),
