@@ -45,7 +45,10 @@ def test_conv1x1_fwd(dtype, tol, P, cin, cout, act):
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("P,cin,cout", [(1024, 64, 128), (1000, 128, 64), (37, 64, 12), (256, 12, 128), (2048, 64, 256),
-                                        (1536, 64, 512)])   # 512 outputs: mix_head_B at d = 128 (BASELINE configs[3])
+                                        (1536, 64, 512),    # 512 outputs: mix_head_B at d = 128 (BASELINE configs[3])
+                                        # 12-channel heads on whole 64-row tiles (flat staging of the gradient rows), and narrow
+                                        # layers whose INPUT rows are not 16-byte multiples (must stay on the generic staging)
+                                        (8192, 64, 12), (640, 32, 12), (128, 4, 4), (192, 12, 12)])
 @pytest.mark.parametrize("act", [0, 1])
 def test_conv1x1_bwd(dtype, tol, P, cin, cout, act):
     from frl_hip import ops

@@ -17,6 +17,7 @@
 // Output: per-workgroup float32 slabs in the layout of the generic kernel (tap-major), summed in a fixed order by slab_reduce_t.
 #include "frl_common.hpp"
 #include "frl_host.hpp"
+#include <type_traits>
 
 #define C3V_TH 8
 #define C3V_TW 32
@@ -87,17 +88,19 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_band_kernel(const bf16* __r
     int b, y0, x0, ck;
     item_geom(i, b, y0, x0, ck);
     const bf16* xb = X + (((int64_t)b * H) * W) * Cin + ck;
+    int lane_ = lane;
+    asm volatile("" : "+v"(lane_));                              // (opaque: the per-piece lane constants are rebuilt per item, not kept in 40 registers)
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int piece = j * 8 + wave;
       if (piece < C3V_NPIECE) {                                  // (wave-uniform)
-        const int chunk = piece * 64 + lane;
+        const int chunk = piece * 64 + lane_;
         const int hp = chunk >> 3, c = chunk & 7;
         const int hr = (hp * 1928) >> 16, hc = hp - hr * C3V_HP;  // hp / 34 for hp < 344
         const int gy = y0 + hr - 1, gx = x0 + hc - 1;
         const bool ok = hp < C3V_HPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
         const bf16* src = ok ? xb + ((int64_t)gy * W + gx) * Cin + ((c ^ (c3v_f(hc) << 1)) << 3)
-                             : reinterpret_cast<const bf16*>(c3v_zero_page) + (lane << 3);
+                             : reinterpret_cast<const bf16*>(c3v_zero_page) + (lane_ << 3);
         const int ldst = dst + piece * 1024;
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -110,9 +113,11 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_band_kernel(const bf16* __r
   auto fetch_dy = [&](int i) {
     int b, y0, x0, ck;
     item_geom(i, b, y0, x0, ck);
+    int tid_ = tid;
+    asm volatile("" : "+v"(tid_));
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int v = tid + 512 * u;
+      const int v = tid_ + 512 * u;
       const int px = v >> 3, c = v & 7;
       const int64_t off = (((int64_t)b * H + y0 + (px >> 5)) * W + x0 + (px & 31)) * Cout + oc_base + c * 8;
       ra[u] = *reinterpret_cast<const bf16x8*>(dY + off);
@@ -120,9 +125,11 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_band_kernel(const bf16* __r
     }
   };
   auto commit_dy = [&](int dst) {
+    int tid_ = tid;
+    asm volatile("" : "+v"(tid_));
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int v = tid + 512 * u;
+      const int v = tid_ + 512 * u;
       const int px = v >> 3, c = v & 7;
       bf16x8 val = ra[u];
       if (Ymask != nullptr) {
@@ -140,19 +147,17 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_band_kernel(const bf16* __r
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) acc[tap][o] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const bf16 one_ = (r16 == 0) ? (bf16)1.f : (bf16)0.f;
-  const bf16x8 ones = bf16x8{one_, one_, one_, one_, one_, one_, one_, one_};
 
   auto write_chunk = [&](int ck) {                               // slab part of one input-channel chunk, then clear the accumulators
+    int lane_ = lane;
+    asm volatile("" : "+v"(lane_));                              // (slab addresses are built here, not carried through the item loop)
+    float* mine = my + (int64_t)(og * 32 + (lane_ >> 4) * 4) * Cin + ck + ib * 16 + (lane_ & 15);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
       for (int o = 0; o < 2; ++o) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ocl = (og * 2 + o) * 16 + kc * 4 + r, ic = ck + ib * 16 + r16;
-          my[((int64_t)tap * 64 + ocl) * Cin + ic] = acc[tap][o][r];
-        }
+        for (int r = 0; r < 4; ++r) mine[((int64_t)tap * 64 + o * 16 + r) * Cin] = acc[tap][o][r];
         acc[tap][o] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
   };
@@ -171,25 +176,36 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_band_kernel(const bf16* __r
       dma_halo(i + 1, 2 * C3V_DY_BYTES + (cur ^ 1) * C3V_HALO_BYTES);
       fetch_dy(i + 1);
     }
-    const bool first_chunk = i < ntl;                            // (uniform) the bias gradient rides with input chunk 0
+    // (fully unrolled, the compiler shares the X fragments of a halo row between the taps of three k-steps: 104 instead of 176 LDS
+    // reads per item)
+    // (two copies of the fully unrolled k loop, so that the bias MFMAs of the (input chunk 0, ib == 0) waves cost the others no branch
+    // inside it: a branch per k-step ends the basic block and with it the overlap of one step's LDS reads with the previous MFMAs)
+    auto contract = [&](auto with_bias) {
+      int r16_ = r16;
+      asm volatile("" : "+v"(r16_));
+      const bf16 one_ = (r16_ == 0) ? (bf16)1.f : (bf16)0.f;       // B operand that sums the k dimension into output column 0
+      const bf16x8 ones = bf16x8{one_, one_, one_, one_, one_, one_, one_, one_};
 #pragma unroll
-    for (int ks = 0; ks < C3V_TH; ++ks) {
-      bf16x8 af[2];
+      for (int ks = 0; ks < C3V_TH; ++ks) {
+        bf16x8 af[2];
 #pragma unroll
-      for (int o = 0; o < 2; ++o) af[o] = c3v_tr8(smem, dyb + ks * (C3V_TW * 128) + aoff[o][0], dyb + ks * (C3V_TW * 128) + aoff[o][1]);
-      if (first_chunk && ib == 0) {
+        for (int o = 0; o < 2; ++o) af[o] = c3v_tr8(smem, dyb + ks * (C3V_TW * 128) + aoff[o][0], dyb + ks * (C3V_TW * 128) + aoff[o][1]);
+        if constexpr (decltype(with_bias)::value) {
 #pragma unroll
-        for (int o = 0; o < 2; ++o) accb[o] = mfma16(af[o], ones, accb[o]);
+          for (int o = 0; o < 2; ++o) accb[o] = mfma16(af[o], ones, accb[o]);
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int dy = tap / 3, dx = tap % 3;
+          const int ro = hb + (ks + dy) * (C3V_HP * 128);
+          const bf16x8 bfr = c3v_tr8(smem, ro + boff[dx][0], ro + boff[dx][1]);
+#pragma unroll
+          for (int o = 0; o < 2; ++o) acc[tap][o] = mfma16(af[o], bfr, acc[tap][o]);
+        }
       }
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3, dx = tap % 3;
-        const int ro = hb + (ks + dy) * (C3V_HP * 128);
-        const bf16x8 bfr = c3v_tr8(smem, ro + boff[dx][0], ro + boff[dx][1]);
-#pragma unroll
-        for (int o = 0; o < 2; ++o) acc[tap][o] = mfma16(af[o], bfr, acc[tap][o]);
-      }
-    }
+    };
+    if (i < ntl && ib == 0) contract(std::true_type{});           // (uniform) the bias gradient rides with input chunk 0
+    else contract(std::false_type{});
     if (i + 1 < nitems) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // dY / Y registers and this wave's DMA pieces have landed
       commit_dy((cur ^ 1) * C3V_DY_BYTES);

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(
   // flatA: rows of dY are shorter than a 16-byte vector multiple (the 12-channel heads) but contiguous: a whole 64-row tile is copied
   // as ONE flat run of 16-byte vectors and stays flat in LDS (row pitch = Cout; the 8-byte transposing reads only need Cout % 4 == 0;
   // the columns a fragment reads beyond Cout belong to output channels that are never written)
-  const bool flatA = sizeof(T) == 2 && (Cout % VEC) != 0 && (Cout % 4) == 0 && ldy == Cout && (P % WG_KP) == 0;
+  const bool flatA = sizeof(T) == 2 && (Cout % VEC) != 0 && (Cout % 4) == 0 && ldy == Cout && (P % WG_KP) == 0 && (Cin % VEC) == 0;
   const bool fastA = ((Cout % VEC) == 0 && (ldy % VEC) == 0) || flatA, fastB = (Cin % VEC) == 0;
   const bool fast = fastA && fastB;                          // 16-byte channel vectors: tiles are prefetched into registers
   const int pA = flatA ? Cout : pitchA;                      // row pitch of the staged dY tile (elements)
