@@ -101,6 +101,21 @@ int frl_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const f
                       const float* rstd, void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int G, int relu,
                       int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
 
+/* ---- fused two-layer type encoder (csrc/enc_fused.hip) -----------------------------------------------------------
+ * conv1x1 C0->C1 (no bias) -> GroupNorm(G1) -> ReLU -> conv1x1 C1->C2 (no bias) -> GroupNorm(G2): Conv2DEncoder with two layers
+ * (frl/models/conv2d_encoder.py:100-159) as ONE launch per direction, one workgroup per sample; the 128-channel intermediates never
+ * reach HBM in the forward.  frl_encoder2_supported: 1 for (64, 128, 64, 8, 8, HW % 16 == 0, FRL_BF16), else compose
+ * frl_conv1x1_* / frl_groupnorm_*.  stats [B][32] f32 = mean1[8] rstd1[8] mean2[8] rstd2[8].
+ * Backward (parameters only: the encoder's input is data): dw1 [C1][C0], dw2 [C2][C1] and the GroupNorm parameter gradients; the chain
+ * is recomputed per pass and the weight gradients are contracted inside the kernel, so no intermediate tensor reaches HBM. */
+int frl_encoder2_supported(int C0, int C1, int C2, int G1, int G2, int HW, int dtype);
+size_t frl_encoder2_workspace_bytes(int B);
+int frl_encoder2_fwd(const void* x, const float* w1, const float* g1, const float* b1, const float* w2, const float* g2, const float* b2,
+                     void* z, float* stats, int B, int HW, float eps, void* ws, size_t ws_bytes, frl_stream_t stream);
+int frl_encoder2_bwd(const void* x, const void* dz, const float* w1, const float* g1, const float* b1, const float* w2, const float* g2,
+                     const float* b2, const float* stats, float* dw1, float* dg1, float* db1, float* dw2, float* dg2, float* db2,
+                     int B, int HW, void* ws, size_t ws_bytes, frl_stream_t stream);
+
 /* ---- EdgeAwareSmoothingConv2D fixed stencils -------------------------------------------------------------------
  * Sobel/4 depthwise gradients (frl/models/spatial.py:240-249,295-296): g [B][H][W][2C] = cat[dx, dy]. */
 int frl_sobel_fwd(const void* x, void* g, int B, int H, int W, int C, int dtype, frl_stream_t stream);

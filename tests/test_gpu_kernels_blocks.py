@@ -84,6 +84,51 @@ def test_conv3x3(dtype, atol, wtol, B, H, W, cin, cout, act):
         assert rel_err(dw, w2.grad) <= wtol * 2 and rel_err(db, b2.grad) <= wtol * 2
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 32, 32), (5, 16, 16), (2, 4, 8)])
+def test_fused_two_layer_encoder_matches_float64_and_the_modular_path(B, H, W):
+    """Conv2DEncoder 64 -> 128 -> 64 (bf16): the one-launch-per-direction kernels (csrc/enc_fused.hip) against float64 autograd of
+    conv1x1 -> GroupNorm(8) -> ReLU -> conv1x1 -> GroupNorm(8), and against the modular kernels on the same inputs."""
+    from frl_hip.models.blocks import Conv2DEncoder
+    g = torch.Generator().manual_seed(B * H + W)
+    torch.manual_seed(B * H + W)                                    # (the constructor draws the convolution weights from the global generator)
+    enc = Conv2DEncoder(64, [128, 64], num_groups=8)
+    with torch.no_grad():
+        for prm in enc.parameters():
+            if prm.dim() == 1:
+                prm.copy_(torch.randn(prm.shape, generator=g) * 0.3 + (1.0 if prm.mean() > 0.5 else 0.0))
+    x = q(torch.randn(B, 64, H, W, generator=g) * 1.3 + 0.2, torch.bfloat16)
+    dz = q(torch.randn(B, 64, H, W, generator=g), torch.bfloat16)
+    names = [n for n, _ in enc.named_parameters()]
+    # float64 reference (weights as the kernels see them: rounded to bf16)
+    ps = {n: (q(p.detach(), torch.bfloat16) if p.dim() == 4 else p.detach().double()).requires_grad_(True) for n, p in enc.named_parameters()}
+    convs = [n for n in names if ps[n].dim() == 4]
+    gam = [n for n in names if n.endswith("weight") and ps[n].dim() == 1]
+    bet = [n for n in names if n.endswith("bias") and ps[n].dim() == 1]
+    y = F.relu(O.group_norm(F.conv2d(x, ps[convs[0]]), 8, ps[gam[0]], ps[bet[0]]))
+    zr = O.group_norm(F.conv2d(y, ps[convs[1]]), 8, ps[gam[1]], ps[bet[1]])
+    zr.backward(dz)
+    enc = enc.to(DEV).train()
+    xd, dzd = nhwc(x).to(torch.bfloat16).to(DEV), nhwc(dz).to(torch.bfloat16).to(DEV)
+    out = {}
+    for fuse in (True, False):
+        enc.fuse = fuse
+        enc.zero_grad(set_to_none=True)
+        z = enc(xd)
+        z.backward(dzd)
+        out[fuse] = (z.detach().float().cpu(), {n: p.grad.detach().cpu().double().reshape(ps[n].shape) for n, p in enc.named_parameters()})
+    assert enc._fused_layers(xd) is None and out[True][0].shape == out[False][0].shape   # (fuse is off now)
+    for fuse in (True, False):
+        z, grads = out[fuse]
+        assert rel_err(z, nhwc(zr.detach())) <= 3e-2, fuse
+        for n in names:
+            if H * W >= 256:                                        # (32-pixel samples: the bf16 rounding of dh, dy1, dy2 dominates the cancelling sums)
+                assert rel_err(grads[n], ps[n].grad) <= 1e-1, (fuse, n)
+    # fused and modular round at the same places: they agree far below the bf16 tolerance
+    assert rel_err(out[True][0], out[False][0].double()) <= 1.6e-2
+    for n in names:
+        assert rel_err(out[True][1][n], out[False][1][n]) <= 1e-2, n
+
+
 @pytest.mark.parametrize("dtype,atol,wtol", MODES)
 @pytest.mark.parametrize("B,H,W,C", [(2, 32, 32, 64), (1, 8, 8, 8), (1, 9, 13, 16)])
 def test_sobel(dtype, atol, wtol, B, H, W, C):

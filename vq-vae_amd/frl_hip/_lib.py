@@ -55,6 +55,10 @@ SIGNATURES = {
     "frl_groupnorm_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, F, I, I, P]),
     "frl_groupnorm_bwd_workspace_bytes": (S, [I, I, I]),
     "frl_groupnorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P, S, P]),
+    "frl_encoder2_supported": (c_int, [I, I, I, I, I, I, I]),
+    "frl_encoder2_workspace_bytes": (S, [I]),
+    "frl_encoder2_fwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, F, P, S, P]),
+    "frl_encoder2_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P, S, P]),
     "frl_decoder_mse_fused_supported": (c_int, [I, I, I, I]),
     "frl_decoder_mse_workspace_bytes": (S, [L, I]),
     "frl_decoder_mse_fwd": (c_int, [P, P, P, P, P, P, P, P, P, L, I, P, S, P]),

@@ -81,6 +81,23 @@ class GroupNormFn(Function):
         return dx, dg, db, None, None, None
 
 
+class Encoder2Fn(Function):
+    """Fused conv1x1 -> GroupNorm -> ReLU -> conv1x1 -> GroupNorm over the rows of each sample (csrc/enc_fused.hip); x is data (no dx)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, eps):
+        z, stats = ops.encoder2_fwd(x, w1, g1, b1, w2, g2, b2, eps)
+        ctx.save_for_backward(x, w1, g1, b1, w2, g2, b2, stats)
+        return z
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz):
+        x, w1, g1, b1, w2, g2, b2, stats = ctx.saved_tensors
+        dw1, dg1, db1, dw2, dg2, db2 = ops.encoder2_bwd(x, _c(dz), w1, g1, b1, w2, g2, b2, stats)
+        return None, dw1, dg1, db1, dw2, dg2, db2, None
+
+
 class SobelFn(Function):
     @staticmethod
     def forward(ctx, x):
@@ -277,6 +294,10 @@ def conv1x1(x, w, bias=None, act=ACT_NONE):
 
 def conv3x3(x, w, bias=None, act=ACT_NONE):
     return Conv3x3Fn.apply(x, w, bias, act)
+
+
+def encoder2(x, w1, g1, b1, w2, g2, b2, eps=1e-5):
+    return Encoder2Fn.apply(x, w1, g1, b1, w2, g2, b2, eps)
 
 
 def group_norm(x, gamma, beta, groups, eps=1e-5, relu=False):

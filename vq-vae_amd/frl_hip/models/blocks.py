@@ -132,7 +132,30 @@ class Conv2DEncoder(nn.Module):
     def set_input_dropout_rate(self, rate: float) -> None:
         self.input_dropout.p = rate
 
+    fuse = True        # the two-layer bf16 configuration runs as one launch per direction (csrc/enc_fused.hip) when nothing prevents it
+
+    def _fused_layers(self, x: torch.Tensor):
+        """(conv1, norm1, conv2, norm2) when the fused kernels apply to this call, else None."""
+        mods = list(self.layers)
+        convs = [m for m in mods if isinstance(m, Conv2dParams)]
+        norms = [m for m in mods if isinstance(m, GroupNormParams)]
+        if not self.fuse or len(convs) != 2 or len(norms) != 2 or x.dtype != torch.bfloat16 or not x.is_cuda or x.requires_grad:
+            return None
+        if self.training and (self.input_dropout.p > 0 or any(isinstance(m, _Marker) and m.kind == "dropout2d" and m.p > 0 for m in mods)):
+            return None
+        if any(c.bias is not None for c in convs) or norms[0].eps != norms[1].eps:
+            return None
+        hw = x.numel() // (x.shape[0] * x.shape[-1])
+        if not ops.encoder2_supported(convs[0].weight.shape[1], convs[0].weight.shape[0], convs[1].weight.shape[0], norms[0].num_groups,
+                                         norms[1].num_groups, hw, x.dtype):
+            return None
+        return convs[0], norms[0], convs[1], norms[1]
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        fused = self._fused_layers(x)
+        if fused is not None:
+            c1, n1, c2, n2 = fused
+            return Fh.encoder2(x, c1.weight, n1.weight, n1.bias, c2.weight, n2.weight, n2.bias, n1.eps)
         hw = x.shape[1] * x.shape[2]
         x = channel_dropout(x, self.input_dropout.p, self.training, hw)
         i = 0

@@ -281,6 +281,41 @@ def vq_ema_update(sums, counts, ema_count, ema_sum, codebook, decay: float, eps:
 # ----------------------------------------------------------------------------------------------
 # GroupNorm over NHWC rows (csrc/norm.hip)
 # ----------------------------------------------------------------------------------------------
+def encoder2_supported(c0: int, c1: int, c2: int, g1: int, g2: int, hw: int, dtype) -> bool:
+    return bool(_lib.load().frl_encoder2_supported(c0, c1, c2, g1, g2, hw, 1 if dtype == torch.bfloat16 else 0))
+
+
+@_timed("encoder2_fwd")
+def encoder2_fwd(x, w1, g1, b1, w2, g2, b2, eps: float = 1e-5):
+    """Fused conv1x1 -> GroupNorm -> ReLU -> conv1x1 -> GroupNorm (csrc/enc_fused.hip).  x [B, ..., 64] bf16 -> (z, stats [B, 32])."""
+    b, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (b * c)
+    _chk_rows(x, c, "encoder2.x")
+    lib = _lib.load()
+    z = torch.empty(x.shape[:-1] + (w2.shape[0],), dtype=x.dtype, device=x.device)
+    stats = torch.empty(b, 32, dtype=torch.float32, device=x.device)
+    ws = workspace(lib.frl_encoder2_workspace_bytes(b), x.device)
+    check(lib.frl_encoder2_fwd(_p(x), _p(_f32(w1, "w1")), _p(_f32(g1, "g1")), _p(_f32(b1, "b1")), _p(_f32(w2, "w2")), _p(_f32(g2, "g2")),
+                               _p(_f32(b2, "b2")), _p(z), _p(stats), b, hw, float(eps), _p(ws), ws.numel(), _stream()), "frl_encoder2_fwd")
+    return z, stats
+
+
+@_timed("encoder2_bwd")
+def encoder2_bwd(x, dz, w1, g1, b1, w2, g2, b2, stats):
+    """-> (dw1, dg1, db1, dw2, dg2, db2): parameter gradients of the fused encoder (its input is data: no dx)."""
+    b, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (b * c)
+    lib = _lib.load()
+    dw1 = torch.empty(w1.shape, dtype=torch.float32, device=x.device)
+    dw2 = torch.empty(w2.shape, dtype=torch.float32, device=x.device)
+    dg1, db1 = torch.empty_like(g1), torch.empty_like(b1)
+    dg2, db2 = torch.empty_like(g2), torch.empty_like(b2)
+    ws = workspace(lib.frl_encoder2_workspace_bytes(b), x.device)
+    check(lib.frl_encoder2_bwd(_p(x), _p(dz), _p(_f32(w1, "w1")), _p(g1), _p(b1), _p(_f32(w2, "w2")), _p(g2), _p(b2), _p(stats), _p(dw1), _p(dg1),
+                               _p(db1), _p(dw2), _p(dg2), _p(db2), b, hw, _p(ws), ws.numel(), _stream()), "frl_encoder2_bwd")
+    return dw1, dg1, db1, dw2, dg2, db2
+
+
 @_timed("groupnorm_fwd")
 def groupnorm_fwd(x: torch.Tensor, gamma, beta, groups: int, eps: float = 1e-5, relu: bool = False):
     """x [B, ..., C] -> (y, mean [B,G], rstd [B,G])."""
