@@ -101,6 +101,12 @@ int frl_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const f
                       const float* rstd, void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int G, int relu,
                       int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
 
+/* ---- loss head (csrc/elementwise.hip) ----------------------------------------------------------------------------
+ * out[0] = sum_i coef[i] * *terms[i] (device scalars, host coefficients, n <= 8), ok_out[0] (optional) = 1 if out[0] is finite else 0: the weighted
+ * sum of the loss terms (scripts/train_vqvae.py:236-248) and the isfinite guard (step.py:1057-1074) in one launch; its backward. */
+int frl_scalar_combine(const float* const* terms_host, const float* coef_host, int n, float* out, float* ok_out, frl_stream_t stream);
+int frl_scalar_fanout(const float* g, const float* coef_host, int n, float* out, frl_stream_t stream);
+
 /* ---- fused two-layer type encoder (csrc/enc_fused.hip) -----------------------------------------------------------
  * conv1x1 C0->C1 (no bias) -> GroupNorm(G1) -> ReLU -> conv1x1 C1->C2 (no bias) -> GroupNorm(G2): Conv2DEncoder with two layers
  * (frl/models/conv2d_encoder.py:100-159) as ONE launch per direction, one workgroup per sample; the 128-channel intermediates never

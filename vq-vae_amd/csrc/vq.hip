@@ -761,7 +761,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_resident
       stats_out[0] = (float)red[0];
       stats_out[1] = (float)exp(-red[NW]);
       stats_out[2] = (float)__hip_atomic_load(&ctl->namb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      stats_out[3] = 0.f;
+      stats_out[3] = (float)(red[0] / ((double)N * (double)d));   // mean squared error (the two VQ loss terms)
       __hip_atomic_store(&ctl->namb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&ctl->done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -951,7 +951,7 @@ struct HistEpi {
 
 // stats = {sqerr_sum, perplexity, n_re-evaluated, 0}
 __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restrict__ partial, int npartial, const VqHeader* __restrict__ hdr,
-                                                          const int32_t* __restrict__ counts, int K, int64_t N, float* __restrict__ stats) {
+                                                          const int32_t* __restrict__ counts, int K, int64_t N, int d, float* __restrict__ stats) {
   __shared__ double red[256];
   double s = 0.0;
   for (int i = threadIdx.x; i < npartial; i += 256) s += (double)partial[i];
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restric
     stats[0] = (float)sq;
     stats[1] = (float)exp(-red[0]);
     stats[2] = (float)hdr->namb;
-    stats[3] = 0.f;
+    stats[3] = (float)(sq / ((double)N * (double)d));
   }
 }
 
@@ -1409,7 +1409,7 @@ static int launch_vq(const void* z, const float* E, char* prep, int64_t N, int K
   }
   launch_slab_reduce<int32_t, HistEpi>((const int32_t*)(ws + L.hist), L.grid, K, HistEpi{(const int32_t*)(ws + L.counts_fix), counts}, st);
   FRL_LAUNCH(vq_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)(ws + L.partial), L.grid * nw, (const VqHeader*)hdr,
-             (const int32_t*)counts, K, N, stats);
+             (const int32_t*)counts, K, N, d, stats);
   return frl_check_launch("vq_assign");
 }
 
@@ -1488,7 +1488,7 @@ int frl_vq_prepare(const float* E, int64_t N, int K, int d, int dtype, void* pre
 
 // z [N][d] (dtype), E [K][d] f32 master codebook.  Outputs: idx_out [N] int32, zq_out [N][d] (dtype, the
 // codebook rows rounded to dtype), stats_out [4] f32 = {sum ||z - z_q||^2, perplexity, #rows re-evaluated in
-// float64, 0}, counts_out [K] int32 code usage.  In bf16 mode distances are taken to the bf16-rounded codebook.
+// float64, mean squared error = sum / (N d)}, counts_out [K] int32 code usage.  In bf16 mode distances are taken to the bf16-rounded codebook.
 // prep: NULL, or the image frl_vq_prepare wrote for THIS codebook content, dtype and row count class.  The image carries the kernel's
 // arrival counter and histogram accumulator (zeroed by frl_vq_prepare, left zeroed by every call): one call in flight per image.
 int frl_vq_assign_fwd_prepared(const void* z, const float* E, void* prep, int64_t N, int K, int d, int32_t* idx_out, void* zq_out,

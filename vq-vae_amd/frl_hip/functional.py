@@ -98,6 +98,35 @@ class Encoder2Fn(Function):
         return None, dw1, dg1, db1, dw2, dg2, db2, None
 
 
+class ScalarCombineFn(Function):
+    """sum_i coef_i * term_i over device scalars in one launch (plus its finite flag); backward: one launch for all term gradients."""
+
+    @staticmethod
+    def forward(ctx, coefs, *terms):
+        loss, ok = ops.scalar_combine([t.detach() for t in terms], coefs)
+        ctx.coefs = tuple(float(c) for c in coefs)
+        ctx.mark_non_differentiable(ok)
+        return loss, ok
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, g_ok):
+        gg = ops.scalar_fanout(g.reshape(1).float().contiguous(), ctx.coefs)
+        return (None,) + tuple(gg[i] for i in range(len(ctx.coefs)))
+
+
+def scalar_combine(terms, coefs):
+    """-> (sum_i coef_i * term_i [0-dim], ok [1] = 1.0 if finite else 0.0 | None); plain torch arithmetic off the GPU path."""
+    fits = all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.numel() == 1 for t in terms) and 1 <= len(terms) <= 8
+    if not fits:
+        tot = None
+        for t, c in zip(terms, coefs):
+            v = t if c == 1.0 else c * t
+            tot = v if tot is None else tot + v
+        return tot, None
+    return ScalarCombineFn.apply(tuple(coefs), *[t.reshape(()) for t in terms])
+
+
 class SobelFn(Function):
     @staticmethod
     def forward(ctx, x):
@@ -226,19 +255,23 @@ class VQFn(Function):
         n = z.numel() // d
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(z, codebook, idx, counts, zq)
-        mse = stats[0] / float(n * d)
         ctx.mark_non_differentiable(idx, counts)
-        return zq, mse, mse.clone(), stats[1].clone(), idx, counts
+        # stats = {sum ||z - z_q||^2, perplexity, rows re-evaluated, mean squared error}: the two loss terms are numerically equal
+        mse = stats.narrow(0, 3, 1).reshape(())
+        return zq, mse, mse.clone(), stats.narrow(0, 1, 1).reshape(()), idx, counts
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_zq, g_cb, g_cm, g_perp, g_idx, g_counts):
         z, codebook, idx, counts, zq = ctx.saved_tensors
-        gs = torch.zeros(2, dtype=torch.float32, device=z.device)
-        if g_cm is not None:
-            gs[0] = g_cm
-        if g_cb is not None:
-            gs[1] = g_cb
+        if g_cm is not None and g_cb is not None:
+            gs = torch.stack([g_cm.reshape(()).float(), g_cb.reshape(()).float()])      # one launch
+        else:
+            gs = torch.zeros(2, dtype=torch.float32, device=z.device)
+            if g_cm is not None:
+                gs[0] = g_cm
+            if g_cb is not None:
+                gs[1] = g_cb
         gz, ge, _ = ops.vq_bwd(_c(g_zq), z, codebook, idx, counts, gs, 1.0,
                                want_gz=ctx.needs_input_grad[0], want_ge=ctx.needs_input_grad[1], zq=zq)
         return gz, ge, None
@@ -270,7 +303,7 @@ class DecoderMseFn(Function):
         ctx.save_for_backward(z, w1, b1, w2, b2, target, mask, stats)
         if xhat is not None:
             ctx.mark_non_differentiable(xhat)
-        return stats[0].clone(), xhat
+        return stats.narrow(0, 0, 1).reshape(()), xhat                 # (a view of the kernel's output record: no copy launch)
 
     @staticmethod
     @once_differentiable

@@ -23,11 +23,6 @@ from .blocks import Conv2DHead
 from .representation import RepresentationModel
 
 
-def _weighted(weight: float, term: torch.Tensor) -> torch.Tensor:
-    """weight * term; a weight of exactly 1.0 (the default) costs no kernel in forward or backward."""
-    return term if weight == 1.0 else weight * term
-
-
 class VectorQuantizer(nn.Module):
     """argmin-L2 codebook lookup with straight-through estimator; 'st' (gradient) or 'ema' codebook updates."""
 
@@ -66,7 +61,7 @@ class VectorQuantizer(nn.Module):
         zq, l_cb, l_cm, perp, idx, counts = Fh.VQFn.apply(z_rows, self.codebook, self.prepared(z_rows.dtype, z_rows.shape[0]))
         self.last_counts = counts
         if self.quantizer == "ema":
-            vq_loss = self.beta * l_cm
+            vq_loss = Fh.scalar_combine([l_cm], [self.beta])[0]
             if self.training:
                 with torch.no_grad():
                     _, _, sums = ops.vq_bwd(None, z_rows.detach(), self.codebook.detach(), idx, counts, None, 0.0,
@@ -75,7 +70,7 @@ class VectorQuantizer(nn.Module):
                 if not self.defer_ema:
                     self.apply_ema()
         else:
-            vq_loss = l_cb + self.beta * l_cm
+            vq_loss = Fh.scalar_combine([l_cb, l_cm], [1.0, self.beta])[0]       # one launch (and one in the backward)
         return zq, vq_loss, perp, idx
 
     @torch.no_grad()
@@ -181,18 +176,18 @@ class VQVAE(RepresentationModel):
         out: Dict[str, torch.Tensor] = {}
         z_phase = self.forward_phase_nhwc(tile, z_type_detached)            # [B,T,H,W,zp]
         zp_in = z_phase
-        terms = None
+        terms = []                                                          # (loss term, weight) pairs, summed by forward_tiles in one launch
         if hasattr(self, "quant_phase"):
             zpq, pvq, pperp, pidx = self.quant_phase(z_phase.reshape(-1, z_phase.shape[-1]))
             zp_in = zpq.reshape(z_phase.shape)
-            terms = _weighted(self.lambda_vq, pvq)
+            terms.append((pvq, self.lambda_vq))
             out.update(idx_phase=pidx, vq_loss_phase=pvq, perplexity_phase=pperp)
         if mask is None or mask.dim() == 4:                                 # [B,T,H,W]: per-observation validity from the tile ingest
             pmask = mask
         else:
             pmask = mask.unsqueeze(1).expand(b, t, hh, ww).contiguous()
         l_phase, xhat_phase = self._decode_loss(self.decoder_phase, zp_in, tile, pmask, return_recon)
-        terms = _weighted(self.lambda_recon, l_phase) if terms is None else terms + _weighted(self.lambda_recon, l_phase)
+        terms.append((l_phase, self.lambda_recon))
         out.update(z_phase=z_phase, l_phase=l_phase, loss_terms=terms)
         if xhat_phase is not None:
             out["xhat_phase"] = xhat_phase
@@ -228,7 +223,7 @@ class VQVAE(RepresentationModel):
         out = dict(z_type=z_type, gate=gate, idx=idx, vq_loss=vq_loss, perplexity=perp, l_type=l_type)
         if xhat_type is not None:
             out["xhat_type"] = xhat_type
-        loss = _weighted(self.lambda_recon, l_type) + _weighted(self.lambda_vq, vq_loss)
+        terms = [(l_type, self.lambda_recon), (vq_loss, self.lambda_vq)]
         if self.phase:
             if side is not None:
                 main.wait_stream(side)
@@ -237,9 +232,13 @@ class VQVAE(RepresentationModel):
                         v.record_stream(main)
             else:
                 ph = self._phase_branch(tile, z_type.detach(), mask, return_recon)
-            loss = loss + ph.pop("loss_terms")
+            terms += ph.pop("loss_terms")
             out.update(ph)
+        # weighted sum of the loss terms and its isfinite flag in ONE launch (the trainer's device-side guard reads out["loss_ok"])
+        loss, ok = Fh.scalar_combine([t for t, _ in terms], [float(w) for _, w in terms])
         out["loss"] = loss
+        if ok is not None:
+            out["loss_ok"] = ok
         if self.codebook_manager is not None and hasattr(self.codebook_manager, "update") and self.training:
             self._pending_manager = (self.quant.last_counts, z_type.detach().reshape(-1, d))
             if not self.defer_codebook_hooks:

@@ -281,6 +281,30 @@ def vq_ema_update(sums, counts, ema_count, ema_sum, codebook, decay: float, eps:
 # ----------------------------------------------------------------------------------------------
 # GroupNorm over NHWC rows (csrc/norm.hip)
 # ----------------------------------------------------------------------------------------------
+def scalar_combine(terms, coefs):
+    """[device float scalars], [host floats] -> (value [] f32 = sum coef_i * term_i, ok [1] f32 = 1.0 if the value is finite else 0.0)."""
+    n = len(terms)
+    dev = terms[0].device
+    for t in terms:
+        if t.dtype != torch.float32 or t.numel() != 1 or not t.is_cuda:
+            raise ValueError("scalar_combine: terms are float32 CUDA scalars")
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in terms])
+    cf = (ctypes.c_float * n)(*[float(c) for c in coefs])
+    out = torch.empty((), dtype=torch.float32, device=dev)
+    ok = torch.empty(1, dtype=torch.float32, device=dev)
+    check(_lib.load().frl_scalar_combine(ptrs, cf, n, _p(out), _p(ok), _stream()), "frl_scalar_combine")
+    return out, ok
+
+
+def scalar_fanout(g, coefs):
+    """g device float scalar -> out [n] f32 with out[i] = g * coef_i."""
+    n = len(coefs)
+    cf = (ctypes.c_float * n)(*[float(c) for c in coefs])
+    out = torch.empty(n, dtype=torch.float32, device=g.device)
+    check(_lib.load().frl_scalar_fanout(_p(g), cf, n, _p(out), _stream()), "frl_scalar_fanout")
+    return out
+
+
 def encoder2_supported(c0: int, c1: int, c2: int, g1: int, g2: int, hw: int, dtype) -> bool:
     return bool(_lib.load().frl_encoder2_supported(c0, c1, c2, g1, g2, hw, 1 if dtype == torch.bfloat16 else 0))
 

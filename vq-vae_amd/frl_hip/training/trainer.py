@@ -233,6 +233,15 @@ class VQVAETrainer:
             self.pack_cache.refresh()
             self._pack_versions = [p._version for p in self.params]
 
+    @staticmethod
+    def _finite_flag(out):
+        """device float [1]: 1.0 when the loss is finite.  The model's loss head delivers it with the loss (one launch); otherwise
+        x * 0 == 0 (exact for finite x, false for NaN / +-inf) in three tiny kernels."""
+        ok = out.get("loss_ok")
+        if ok is not None:
+            return ok
+        return (out["loss"].detach().float() * 0.0 == 0.0).float().reshape(1)
+
     def _step_body(self, tile, mask):
         """forward -> device isfinite flag -> backward -> clip + AdamW -> codebook hooks -> fragment-image refresh (no host-side
         schedule, no host sync): the part of `step` that a graph can hold."""
@@ -242,12 +251,12 @@ class VQVAETrainer:
             with self.pack_cache:
                 out = self.model.forward_tiles(tile, mask)
                 loss = out["loss"]
-                ok = (loss.detach().float() * 0.0 == 0.0).float().reshape(1)
+                ok = self._finite_flag(out)
                 loss.backward()
         else:
             out = self.model.forward_tiles(tile, mask)
             loss = out["loss"]
-            ok = (loss.detach().float() * 0.0 == 0.0).float().reshape(1)
+            ok = self._finite_flag(out)
             loss.backward()
         out["grad_norm"] = self.opt.step(self.max_norm, None, ok)
         self._images_refresh()
@@ -287,7 +296,7 @@ class VQVAETrainer:
                 # step.py:1057-1074 (skip the batch on a non-finite loss) evaluated on the device: the flag gates the optimizer
                 # kernels, so the host never waits for the loss and keeps queueing the next step
                 # x * 0 == 0 holds exactly for finite x and fails for NaN / +-inf: isfinite in three tiny kernels instead of six
-                ok = (loss.detach().float() * 0.0 == 0.0).float().reshape(1)
+                ok = self._finite_flag(out)
                 if self.reducer is not None and self.reducer.active:
                     self.reducer.flag_src = 1.0 - ok               # rides in the last gradient bucket: every rank takes the same decision
             elif not self._all_finite(loss):
