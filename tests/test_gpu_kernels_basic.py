@@ -276,3 +276,24 @@ def test_codebook_manager_revives_unused_codes_during_training():
     assert torch.isfinite(out["loss"]).item()
     idx = m.forward_tiles(tiles)["idx"]
     assert (idx >= 32).any().item()                                     # revived codes are in use again
+
+
+def test_loss_head_matches_torch_arithmetic_and_flags_non_finite_values():
+    """frl_scalar_combine / frl_scalar_fanout: the weighted sum of the loss terms, its isfinite flag and the term gradients in one launch
+    each (scripts/train_vqvae.py:236-248, step.py:1057-1074) against plain torch arithmetic."""
+    from frl_hip import functional as Fh
+    dev = _dev()
+    vals, coefs = [0.75, 2.5, -1.25, 3.0], [1.0, 0.25, 2.0, 0.5]
+    terms = [torch.tensor(v, device=dev, requires_grad=True) for v in vals]
+    loss, ok = Fh.scalar_combine(terms, coefs)
+    ref = sum(c * v for c, v in zip(coefs, vals))
+    assert abs(loss.item() - ref) <= 1e-6 * abs(ref) and ok.item() == 1.0
+    (3.0 * loss).backward()
+    for t, c in zip(terms, coefs):
+        assert abs(t.grad.item() - 3.0 * c) <= 1e-6
+    for bad in (float("nan"), float("inf"), -float("inf")):
+        loss, ok = Fh.scalar_combine([torch.tensor(1.0, device=dev), torch.tensor(bad, device=dev)], [1.0, 0.5])
+        assert ok.item() == 0.0 and not torch.isfinite(loss).item()
+    # off the GPU path the same call is plain torch arithmetic without a flag
+    loss, ok = Fh.scalar_combine([torch.tensor(2.0), torch.tensor(3.0)], [1.0, 0.5])
+    assert ok is None and loss.item() == 3.5
