@@ -132,8 +132,8 @@ int frl_edge_smooth_stencil_fwd(const void* x, const void* a_logit, const void* 
                                 void* a_soft, void* b_soft, int B, int H, int W, int C, int R, int coarse_dilation,
                                 int dtype, frl_stream_t stream);
 int frl_edge_smooth_stencil_bwd(const void* d_smoothed, const void* x, const void* a_soft, const void* b_soft, void* dx,
-                                void* da_logit, void* db_logit, int B, int H, int W, int C, int R, int coarse_dilation,
-                                int dtype, frl_stream_t stream);
+                                void* da_logit, void* db_logit, const void* dx_add /* optional: added to dx in the store */, int B, int H,
+                                int W, int C, int R, int coarse_dilation, int dtype, frl_stream_t stream);
 /* out = smoothed + max(gate_raw, min_gate) * residual (spatial.py:333-335); n = element count */
 int frl_gate_blend_fwd(const void* smoothed, const void* residual, const void* gate_raw, float min_gate, void* out,
                        void* gate_out, int64_t n, int dtype, frl_stream_t stream);

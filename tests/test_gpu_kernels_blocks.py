@@ -182,6 +182,11 @@ def test_edge_smooth_stencil(dtype, atol, wtol, B, H, W, C, R):
     assert rel_err(dx.float(), nhwc(x.grad)) <= atol * 3
     assert rel_err(da.float(), nhwc(al.grad)) <= atol * 3
     assert rel_err(db.float(), nhwc(bl.grad)) <= atol * 3
+    # additive term folded into the kernel's dx store (the residual branch of EdgeSmoothFn.backward): da / db unchanged bit for bit
+    r = q(torch.randn(B, C, H, W, generator=g), dtype)
+    dx2, da2, db2 = ops.edge_smooth_bwd(nhwc(ds).to(dtype).to(DEV), xd, asoft, bsoft, R, 3, dx_add=nhwc(r).to(dtype).to(DEV))
+    assert rel_err(dx2.float(), nhwc(x.grad + r)) <= atol * 3
+    assert torch.equal(da2, da) and torch.equal(db2, db)
 
 
 @pytest.mark.parametrize("dtype,atol,wtol", MODES)

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void smooth_fwd_kernel(const T* __restrict__ X
 template <typename T, int V, int R>
 __global__ __launch_bounds__(256) void smooth_bwd_kernel(const T* __restrict__ DS, const T* __restrict__ X, const T* __restrict__ AS,
                                                          const T* __restrict__ BS, T* __restrict__ DX, T* __restrict__ DAL, T* __restrict__ DBL,
-                                                         int B, int H, int W, int C, int dil, int tpp) {
+                                                         const T* __restrict__ DXADD, int B, int H, int W, int C, int dil, int tpp) {
   constexpr int K = 2 * ST_ND;
   const int vpr = C / V;
   const int ppw = 256 / tpp;
@@ -278,6 +278,12 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(const T* __restrict__ D
         for (int r = 0; r < R; ++r)
           DBL[p * ((int64_t)C * R) + (c0 + e) * R + r] = from_f32<T>(Bw[e][r] * (ds[e] * slot[e][r] - dot));
       }
+      if (DXADD != nullptr) {                                   // caller's additive term (the residual branch of EdgeSmoothFn: dx += d_res)
+        float ad[V];
+        if constexpr (V == 1) ad[0] = to_f32(DXADD[p * C + c0]); else Vec<T>::load(DXADD + p * C + c0, ad);
+#pragma unroll
+        for (int e = 0; e < V; ++e) dx[e] += ad[e];
+      }
       Vec<T>::store(DX + p * C + c0, dx);
     }
     // d a_logit: reduce dA over the pixel's channel threads (tpp contiguous lanes), then softmax-over-k backward
@@ -317,7 +323,7 @@ __device__ __forceinline__ float sm_dot4(const bf2 (&b)[2], const bf2 (&a)[2]) {
 __global__ __launch_bounds__(256, 2) void smooth_bwd_bf16r4_kernel(const bf16* __restrict__ DS, const bf16* __restrict__ X,
                                                                    const bf16* __restrict__ AS, const bf16* __restrict__ BS,
                                                                    bf16* __restrict__ DX, bf16* __restrict__ DAL, bf16* __restrict__ DBL,
-                                                                   int B, int H, int W, int dil) {
+                                                                   const bf16* __restrict__ DXADD, int B, int H, int W, int dil) {
   constexpr int K = 2 * ST_ND, R = 4, V = 8, C = 64, VPR = 8;   // 8 threads per pixel == 8 filters: lane cvi keeps filter cvi's dA
   constexpr int PPW = 256 / VPR;
   const int npix = B * H * W;
@@ -434,6 +440,12 @@ __global__ __launch_bounds__(256, 2) void smooth_bwd_bf16r4_kernel(const bf16* _
       bf16* dbp = DBL + p * (C * R) + c0 * R;
 #pragma unroll
       for (int i = 0; i < 4; ++i) Vec<bf16>::store(dbp + 8 * i, ob + 8 * i);
+      if (DXADD != nullptr) {                                   // caller's additive term (dx += d_res of the residual branch)
+        float ad[V];
+        Vec<bf16>::load(DXADD + p * C + c0, ad);
+#pragma unroll
+        for (int e = 0; e < V; ++e) dx[e] += ad[e];
+      }
       Vec<bf16>::store(DX + p * C + c0, dx);
     }
     // ---- d a_logit: softmax-over-k backward; lane cvi holds filter k = cvi:  dA_logit[k][r] = A[k][r] (dA[k][r] - sum_k' A dA)
@@ -585,7 +597,7 @@ static int smooth_dispatch(bool fwd, const void* a0, const void* a1, const void*
       int64_t g2 = (npix + 31) / 32;
       if (g2 > 16384) g2 = 16384;
       FRL_LAUNCH(smooth_bwd_bf16r4_kernel, dim3((unsigned)g2), dim3(256), 0, st, (const bf16*)a0, (const bf16*)a1, (const bf16*)a2,
-                 (const bf16*)a3, (bf16*)o0, (bf16*)o1, (bf16*)o2, B, H, W, dil);
+                 (const bf16*)a3, (bf16*)o0, (bf16*)o1, (bf16*)o2, (const bf16*)o3, B, H, W, dil);
       return frl_check_launch("edge_smooth_stencil_bwd");
     }
   }
@@ -594,7 +606,7 @@ static int smooth_dispatch(bool fwd, const void* a0, const void* a1, const void*
     if (fwd) FRL_LAUNCH((smooth_fwd_kernel<T, V, RR>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)a0, (const T*)a1, \
                                 (const T*)a2, (T*)o0, (T*)o1, (T*)o2, (T*)o3, B, H, W, C, dil, tpp);                     \
     else FRL_LAUNCH((smooth_bwd_kernel<T, V, RR>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)a0, (const T*)a1,      \
-                            (const T*)a2, (const T*)a3, (T*)o0, (T*)o1, (T*)o2, B, H, W, C, dil, tpp);                   \
+                            (const T*)a2, (const T*)a3, (T*)o0, (T*)o1, (T*)o2, (const T*)o3, B, H, W, C, dil, tpp);    \
     return frl_check_launch("edge_smooth_stencil");                                                                     \
   }
   SM_CASE(1) SM_CASE(2) SM_CASE(4)
@@ -636,11 +648,13 @@ int frl_edge_smooth_stencil_fwd(const void* x, const void* a_logit, const void* 
 
 // d_smoothed -> dx (stencil part only), d a_logit, d b_logit
 int frl_edge_smooth_stencil_bwd(const void* d_smoothed, const void* x, const void* a_soft, const void* b_soft, void* dx, void* da_logit,
-                                void* db_logit, int B, int H, int W, int C, int R, int coarse_dilation, int dtype, hipStream_t stream) {
+                                void* db_logit, const void* dx_add, int B, int H, int W, int C, int R, int coarse_dilation, int dtype,
+                                hipStream_t stream) {
+  void* add = const_cast<void*>(dx_add);                         // optional [B][H][W][C] term added to dx in the kernel's store
   if (dtype == FRL_F32 && C % 4 == 0)
-    return smooth_dispatch<float, 4>(false, d_smoothed, x, a_soft, b_soft, dx, da_logit, db_logit, nullptr, B, H, W, C, R, coarse_dilation, stream);
+    return smooth_dispatch<float, 4>(false, d_smoothed, x, a_soft, b_soft, dx, da_logit, db_logit, add, B, H, W, C, R, coarse_dilation, stream);
   if (dtype == FRL_BF16 && C % 8 == 0)
-    return smooth_dispatch<bf16, 8>(false, d_smoothed, x, a_soft, b_soft, dx, da_logit, db_logit, nullptr, B, H, W, C, R, coarse_dilation, stream);
+    return smooth_dispatch<bf16, 8>(false, d_smoothed, x, a_soft, b_soft, dx, da_logit, db_logit, add, B, H, W, C, R, coarse_dilation, stream);
   return frl_fail(-2, "edge_smooth: C must be a multiple of 8 (bf16) / 4 (f32)");
 }
 

@@ -90,7 +90,7 @@ SIGNATURES = {
     "frl_sobel_fwd": (c_int, [P, P, I, I, I, I, I, P]),
     "frl_sobel_bwd": (c_int, [P, P, I, I, I, I, I, P]),
     "frl_edge_smooth_stencil_fwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
-    "frl_edge_smooth_stencil_bwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "frl_edge_smooth_stencil_bwd": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "frl_tcn_block_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, F, I, P, S, P]),
     "frl_tcn_block_bwd_data": (c_int, [P, P, P, P, P, L, I, I, I, I, I, I, P, S, P]),
     "frl_tcn_block_bwd_workspace_bytes": (S, [L, I]),

@@ -154,8 +154,7 @@ class EdgeSmoothFn(Function):
         x, a_soft, b_soft = ctx.saved_tensors
         d_sm, d_res = _c(d_sm), _c(d_res)
         d_tot = ops.add(d_sm, d_res, -1.0)                # residual = x - smoothed
-        dx, da, db = ops.edge_smooth_bwd(d_tot, x, a_soft, b_soft, ctx.rank, ctx.dil)
-        dx = ops.add(dx, d_res, 1.0)
+        dx, da, db = ops.edge_smooth_bwd(d_tot, x, a_soft, b_soft, ctx.rank, ctx.dil, dx_add=d_res)   # + d_res: x feeds the residual directly
         return dx, da, db, None, None
 
 

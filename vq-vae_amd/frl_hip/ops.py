@@ -630,11 +630,14 @@ def edge_smooth_fwd(x, a_logit, b_logit, rank: int, coarse_dilation: int):
 
 
 @_timed("edge_smooth_bwd")
-def edge_smooth_bwd(d_smoothed, x, a_soft, b_soft, rank: int, coarse_dilation: int):
+def edge_smooth_bwd(d_smoothed, x, a_soft, b_soft, rank: int, coarse_dilation: int, dx_add: Optional[torch.Tensor] = None):
+    """dx_add (optional, same shape and dtype as x): added to dx inside the kernel's store (the residual branch's gradient)."""
     b, h, w, c = x.shape
     dx = torch.empty_like(x)
     da, db = torch.empty_like(a_soft), torch.empty_like(b_soft)
-    check(_lib.load().frl_edge_smooth_stencil_bwd(_p(d_smoothed), _p(x), _p(a_soft), _p(b_soft), _p(dx), _p(da), _p(db),
+    if dx_add is not None and (dx_add.shape != x.shape or dx_add.dtype != x.dtype or not dx_add.is_contiguous()):
+        raise ValueError("edge_smooth_bwd: dx_add must match x")
+    check(_lib.load().frl_edge_smooth_stencil_bwd(_p(d_smoothed), _p(x), _p(a_soft), _p(b_soft), _p(dx), _p(da), _p(db), _p(dx_add),
                                                   b, h, w, c, rank, coarse_dilation, _dt(x), _stream()),
           "frl_edge_smooth_stencil_bwd")
     return dx, da, db
