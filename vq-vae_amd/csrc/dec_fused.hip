@@ -61,7 +61,7 @@ __device__ __forceinline__ void dec_chain(float (&h)[32], float (&xh)[16], const
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int NFZ>
-__global__ __launch_bounds__(256) void dec_mse_fwd_kernel(const TT* __restrict__ Z, const frag8* __restrict__ Wpk, const float* __restrict__ b1,
+__global__ __launch_bounds__(256, 4) void dec_mse_fwd_kernel(const TT* __restrict__ Z, const frag8* __restrict__ Wpk, const float* __restrict__ b1,
                                                           const float* __restrict__ b2, const TT* __restrict__ TGT,
                                                           const uint8_t* __restrict__ mask, TT* __restrict__ XHAT, int64_t P, int Cz,
                                                           double* __restrict__ partial) {
@@ -79,18 +79,34 @@ __global__ __launch_bounds__(256) void dec_mse_fwd_kernel(const TT* __restrict__
   const bool fastz = (Cz == 32 * NFZ);
   float sq = 0.f, cnt = 0.f;
   const int64_t ntile = (P + 15) >> 4;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
+  // the next tile's rows are requested before this tile's chain (a wave is otherwise parked for a full memory latency per tile)
+  const int64_t tstep = (int64_t)gridDim.x * 4;
+  LQTile<TT, NFZ> zt, zn;
+  LQTile<TT, 2> tt, tn;
+  {
+    const int64_t t0 = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t r0 = (t0 < ntile ? t0 : 0) * 16 + px;
+    const int64_t rc = r0 < P ? r0 : P - 1;
+    lq_load<TT, NFZ>(zt, Z, rc, Cz, kc, fastz);
+    lq_load<TT, 2>(tt, TGT, rc, DF_F, kc, true);
+  }
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += tstep) {
     int64_t row = tile * 16 + px;
     bool valid = row < P;
     if (!valid) row = P - 1;
     if (valid && mask != nullptr) valid = mask[row] != 0;
-    LQTile<TT, NFZ> zt;
-    lq_load<TT, NFZ>(zt, Z, row, Cz, kc, fastz);
-    LQTile<TT, 2> tt;
-    lq_load<TT, 2>(tt, TGT, row, DF_F, kc, true);
+    {
+      const int64_t tnx = tile + tstep < ntile ? tile + tstep : tile;
+      const int64_t rn = tnx * 16 + px;
+      const int64_t rc = rn < P ? rn : P - 1;
+      lq_load<TT, NFZ>(zn, Z, rc, Cz, kc, fastz);
+      lq_load<TT, 2>(tn, TGT, rc, DF_F, kc, true);
+    }
     float h[32], xh[16];
     LQTile<TT, 4> ht;
-    dec_chain<NFZ>(h, xh, zt, w1, w2, b1q, b2q, ht, lane);
+    int lw = lane;
+    asm volatile("" : "+v"(lw));                                // (opaque per tile: the weight fragments stay in LDS instead of 96 hoisted registers)
+    dec_chain<NFZ>(h, xh, zt, w1, w2, b1q, b2q, ht, lw);
     if (valid) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) { const float d = xh[j] - (float)tt.f[j >> 3][j & 7]; sq = fmaf(d, d, sq); }
@@ -104,6 +120,8 @@ __global__ __launch_bounds__(256) void dec_mse_fwd_kernel(const TT* __restrict__
       xo[0] = o0;
       xo[1] = o1;
     }
+    zt = zn;
+    tt = tn;
   }
   double sd = wave_sum_d((double)sq), cd = wave_sum_d((double)cnt);
   __shared__ double red[8];
@@ -179,16 +197,29 @@ __global__ __launch_bounds__(64 * NW) void dec_mse_bwd_kernel(const TT* __restri
   const bf16x8 ones = (r16 == 0) ? bf16x8{one, one, one, one, one, one, one, one} : bf16x8{zero, zero, zero, zero, zero, zero, zero, zero};
 
   const int64_t nwt = (P + R - 1) / R;
+  // the next round's rows are requested before this round's chain and stay in flight across its weight-gradient phase
+  LQTile<TT, NFZ> zt, zn;
+  LQTile<TT, 2> tt, tn;
+  {
+    const int64_t w0 = (int64_t)blockIdx.x < nwt ? (int64_t)blockIdx.x : 0;
+    const int64_t r0 = w0 * R + prow;
+    const int64_t rc = r0 < P ? r0 : P - 1;
+    lq_load<TT, NFZ>(zt, Z, rc, Cz, kc, fastz);
+    lq_load<TT, 2>(tt, TGT, rc, DF_F, kc, true);
+  }
   for (int64_t wt = blockIdx.x; wt < nwt; wt += gridDim.x) {
     int64_t row = wt * R + prow;
     const bool inb = row < P;
     bool valid = inb;
     if (!inb) row = P - 1;
     if (valid && mask != nullptr) valid = mask[row] != 0;
-    LQTile<TT, NFZ> zt;
-    lq_load<TT, NFZ>(zt, Z, row, Cz, kc, fastz);
-    LQTile<TT, 2> tt;
-    lq_load<TT, 2>(tt, TGT, row, DF_F, kc, true);
+    {
+      const int64_t wn = wt + gridDim.x < nwt ? wt + gridDim.x : wt;
+      const int64_t rn = wn * R + prow;
+      const int64_t rc = rn < P ? rn : P - 1;
+      lq_load<TT, NFZ>(zn, Z, rc, Cz, kc, fastz);
+      lq_load<TT, 2>(tn, TGT, rc, DF_F, kc, true);
+    }
     float h[32], xh[16];
     LQTile<TT, 4> ht;
     dec_chain<NFZ>(h, xh, zt, w1, w2, b1q, b2q, ht, lane);
@@ -224,6 +255,11 @@ __global__ __launch_bounds__(64 * NW) void dec_mse_bwd_kernel(const TT* __restri
           for (int e = 0; e < 8; ++e) o[e] = (bf16)dzacc[(j + e) >> 2][(j + e) & 3];
           *reinterpret_cast<bf16x8*>(dzp + j) = o;
         }
+      } else if ((Cz & 3) == 0) {                              // 12-channel latent rows: 8-byte stores
+#pragma unroll
+        for (int j = 0; j < QZ; j += 4)
+          if (QZ * kc + j < Cz)
+            *reinterpret_cast<bf16x4*>(dzp + j) = bf16x4{(bf16)dzacc[j >> 2][0], (bf16)dzacc[j >> 2][1], (bf16)dzacc[j >> 2][2], (bf16)dzacc[j >> 2][3]};
       } else {
 #pragma unroll
         for (int j = 0; j < QZ; ++j)
@@ -256,6 +292,8 @@ __global__ __launch_bounds__(64 * NW) void dec_mse_bwd_kernel(const TT* __restri
       }
     }
     __syncthreads();
+    zt = zn;
+    tt = tn;
   }
   float* my = slab + (int64_t)blockIdx.x * (DF_F * DF_H + DF_H * CZP + DF_F + DF_H);
 #pragma unroll

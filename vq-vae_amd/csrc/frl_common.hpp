@@ -163,6 +163,19 @@ __device__ __forceinline__ void lq_load(LQTile<T, NF>& t, const T* __restrict__ 
       }
     }
   } else {
+    if constexpr (FE == 8) {
+      if ((C & 3) == 0) {                                   // rows of 4 k channels (the 12-channel heads): 8-byte loads, zeros beyond C
+#pragma unroll
+        for (int s = 0; s < NF; ++s) {
+          bf16x4 lo = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f}, hi = lo;
+          const int c = q * kc + 8 * s;
+          if (c < C) lo = *reinterpret_cast<const bf16x4*>(p + 8 * s);
+          if (c + 4 < C) hi = *reinterpret_cast<const bf16x4*>(p + 8 * s + 4);
+          t.f[s] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int s = 0; s < NF; ++s) {
       if constexpr (FE == 8) {
