@@ -12,7 +12,8 @@
 //     v_min_u32 tracks the running arg-min and ONE v_med3_u32 the runner-up, wave-level min-reduce over
 //     the 4 lane groups by __shfl_xor at the end;
 //   * rows whose runner-up is within the rigorous rounding + truncation bound of the minimum are flagged
-//     (idx = -1 - provisional) and re-evaluated exactly in float64 by vq_fixup (<1 % of rows);
+//     (idx = -1 - provisional) and re-evaluated exactly in float64 (<1 % of rows): inside the kernel when the codebook is resident,
+//     by vq_fixup_tile_kernel (16 rows per wave, candidates screened on the matrix cores) on the multi-chunk path;
 //   * z_q gather, squared-error partial sums and the per-workgroup code histogram are fused in.
 // Roofline: HBM for K <= 1024 (algorithmic bytes/vector = 2*d*s + 4), MFMA for K = 8192.
 #include "frl_common.hpp"
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
     const T* __restrict__ Z, const float* __restrict__ E, const float* __restrict__ en_g, const VqHeader* __restrict__ hdr,
     int64_t N, int K, int d, int Kc, int32_t* __restrict__ idx_out, T* __restrict__ zq_out,
     float* __restrict__ partial /*[grid*NW]*/, int32_t* __restrict__ hist_slab /*[grid][K]*/, VqHeader* __restrict__ hdr_w,
-    int32_t* __restrict__ amb_list, const typename DT<T>::frag_t* __restrict__ pk) {
+    int32_t* __restrict__ amb_list, float* __restrict__ amb_lim, const typename DT<T>::frag_t* __restrict__ pk) {
   typedef typename DT<T>::frag_t frag_t;
   constexpr int FE = DT<T>::FE;
   constexpr int q = NF * FE;                 // channels per lane quarter
@@ -275,7 +276,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
       if (row < N) {
         if (kc == 0) {
           idx_out[row] = amb ? (-1 - code) : code;
-          if (amb) amb_list[atomicAdd(&hdr_w->namb, 1)] = (int32_t)row;
+          if (amb) {
+            const int pos = atomicAdd(&hdr_w->namb, 1);
+            amb_list[pos] = (int32_t)row;
+            // every code whose bias-free f32 score is <= lim may be the float64 arg-min: s1 carries the batch bias Cb, thr bounds the key
+            // truncation and the rounding of both passes
+            amb_lim[pos] = (s1 - Cb) + thr[t] + 2.3841858e-7f * (s1 + Cb);
+          }
         }
         if (!amb) {
           // gather z_q (rounded to T) for this lane's channel quarter, accumulate squared error
@@ -775,172 +782,82 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_resident
 }
 
 // ---------------------------------------------------------------------------------------------
-// exact re-evaluation of the flagged rows (one wave per row, grid-stride over the append list):
-//   pass 1: f32 direct-difference distances to all K codes -> wave minimum m32;
-//   pass 2: codes within the f32 rounding bound of m32 are re-evaluated in float64, first index wins ties.
-// Results per row are independent of the list order; the squared-error sum uses a float64 atomic.
+// Exact re-evaluation of the flagged rows of the multi-chunk path, 16 rows per wave: the rows are re-scored against the WHOLE packed
+// image on the matrix cores (fragments streamed from L2: 2 MB per tile at K = 8192, d = 128, instead of the 4 MB float32 codebook per
+// ROW of the former one-wave-per-row kernels -- 17 ms at 1 % flagged rows), codes under the row's limit are evaluated in float64
+// in-lane (up to two pending per lane, flushed together), first index wins ties.  Row results do not depend on the list order; the
+// squared-error sum uses a float64 atomic, the histogram integer atomics.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void vq_fixup_kernel(const T* __restrict__ Z, const float* __restrict__ E, int K, int d,
-                                                       const int32_t* __restrict__ amb_list, VqHeader* __restrict__ hdr,
-                                                       int32_t* __restrict__ idx_out, T* __restrict__ zq_out,
-                                                       int32_t* __restrict__ counts_fix) {
-  // per wave: z row [d] + a 64-code tile of the (rounded) codebook with pitch d+1 (conflict-free column reads)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+template <typename T, int NF>
+__global__ __launch_bounds__(256) void vq_fixup_tile_kernel(const T* __restrict__ Z, const float* __restrict__ E, const float* __restrict__ en_g,
+                                                            const typename DT<T>::frag_t* __restrict__ pk, int K, int kpad, int d,
+                                                            const int32_t* __restrict__ amb_list, const float* __restrict__ amb_lim,
+                                                            VqHeader* __restrict__ hdr, int32_t* __restrict__ idx_out, T* __restrict__ zq_out,
+                                                            int32_t* __restrict__ counts_fix) {
+  constexpr int FE = DT<T>::FE;
+  constexpr int q = NF * FE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int pitch = d + 1;
-  float* zrow = reinterpret_cast<float*>(smem) + (size_t)wave * (d + 64 * pitch);
-  float* et = zrow + d;
+  const int vx = lane & 15, kc = lane >> 4;
+  const bool fast = (d == 4 * q);
   const int namb = hdr->namb;
-  const int nwaves = gridDim.x * 4;
-  const float slack = 2.f * (float)(d + 8) * 1.1920929e-7f;
-  for (int it = blockIdx.x * 4 + wave; it < namb; it += nwaves) {
-    const int64_t n = amb_list[it];
-    __builtin_amdgcn_wave_barrier();
-    for (int j = lane; j < d; j += 64) zrow[j] = to_f32(Z[n * (int64_t)d + j]);
-    float m32 = 3.0e38f;                       // running f32 minimum (wave-uniform)
-    double best = 1.0e300;
-    int bestk = 0x7fffffff;
-    for (int k0 = 0; k0 < K; k0 += 64) {
-      __builtin_amdgcn_wave_barrier();
-      // cooperative, coalesced load of codes k0..k0+63 (row-major in memory) into the padded LDS tile
-      const int nel = 64 * d;
-      for (int i = lane; i < nel; i += 64) {
-        const int kk = i / d, j = i - kk * d;
-        et[kk * pitch + j] = (k0 + kk < K) ? to_f32(from_f32<T>(E[(int64_t)(k0 + kk) * d + j])) : 0.f;
+  const int ntile = (namb + 15) >> 4, nwaves = gridDim.x * 4, nmb = kpad >> 4;
+  float sq_acc = 0.f;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntile; tile += nwaves) {
+    const int li = tile * 16 + vx;
+    const bool valid = li < namb;
+    const int64_t row = amb_list[valid ? li : tile * 16];
+    const float lm = amb_lim[valid ? li : tile * 16];
+    LQTile<T, NF> zr;
+    lq_load<T, NF>(zr, Z, row, d, kc, fast);
+    double bestd = 1.0e300;
+    int bk = 0x7fffffff, p0 = -1, p1 = -1;
+    auto flush = [&]() {
+      if (p0 >= 0) {
+        double d0, d1;
+        vq_exact_pair<T, 1>(Z, E, row, p0, p1, d, d0, d1);
+        if (d0 < bestd || (d0 == bestd && p0 < bk)) { bestd = d0; bk = p0; }
+        if (p1 >= 0 && (d1 < bestd || (d1 == bestd && p1 < bk))) { bestd = d1; bk = p1; }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const int k = k0 + lane;
-      const float* er = et + lane * pitch;
-      float s = 0.f;
-      for (int j = 0; j < d; ++j) { const float df = zrow[j] - er[j]; s = fmaf(df, df, s); }
-      if (k >= K) s = 3.0e38f;
-      float cm = s;
+      p0 = p1 = -1;
+    };
+#pragma unroll 2
+    for (int mb = 0; mb < nmb; ++mb) {
+      f32x4 acc = *reinterpret_cast<const f32x4*>(en_g + mb * 16 + 4 * kc);
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) cm = fminf(cm, __shfl_xor(cm, off, 64));
-      m32 = fminf(m32, cm);
-      // every code within the f32 rounding bound of the (still decreasing) running minimum is evaluated exactly
-      if (s <= m32 * (1.f + slack) + 1e-30f) {
-        double sd = 0.0;
-        for (int j = 0; j < d; ++j) { const double df = (double)zrow[j] - (double)er[j]; sd += df * df; }
-        if (sd < best) { best = sd; bestk = k; }
+      for (int s = 0; s < NF; ++s) acc = mfma16(pk[(size_t)(mb * NF + s) * 64 + lane], zr.f[s], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int code = mb * 16 + 4 * kc + r;
+        const bool hit = valid && acc[r] <= lm && code < K;
+        if (__builtin_amdgcn_ballot_w64(hit && p1 >= 0) != 0ull) flush();       // a lane with both slots taken: evaluate all pending
+        if (hit) { if (p0 < 0) p0 = code; else p1 = code; }
       }
     }
+    flush();
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const double ob = __shfl_xor(best, off, 64);
-      const int ok = __shfl_xor(bestk, off, 64);
-      if (ob < best || (ob == best && ok < bestk)) { best = ob; bestk = ok; }
+    for (int off = 16; off <= 32; off <<= 1) {
+      const double ob = __shfl_xor(bestd, off, 64);
+      const int okk = __shfl_xor(bk, off, 64);
+      if (ob < bestd || (ob == bestd && okk < bk)) { bestd = ob; bk = okk; }
     }
-    float sq = 0.f;
-    for (int j = lane; j < d; j += 64) {
-      const float ev = to_f32(from_f32<T>(E[(int64_t)bestk * d + j]));
-      zq_out[n * (int64_t)d + j] = from_f32<T>(ev);
-      const float df = zrow[j] - ev;
-      sq = fmaf(df, df, sq);
-    }
-    sq = wave_sum(sq);
-    if (lane == 0) {
-      idx_out[n] = bestk;
-      atomicAdd(&counts_fix[bestk], 1);
-      atomicAdd(&hdr->sq_fix, (double)sq);
-    }
-  }
-}
-
-// Same re-evaluation with the WHOLE (rounded) codebook resident in LDS ([K][d+1] f32, conflict-free column reads): one
-// coalesced fill per workgroup, then each wave walks its share of the flagged rows.  Used when K*(d+1)*4 fits in LDS.
-#define VQ_FIXL_WAVES 8      // waves per workgroup of the LDS-resident fix-up: one flagged row per wave at a time
-template <typename T>
-__global__ __launch_bounds__(64 * VQ_FIXL_WAVES) void vq_fixup_lds_kernel(const T* __restrict__ Z, const float* __restrict__ E, int K, int d,
-                                                           const int32_t* __restrict__ amb_list, VqHeader* __restrict__ hdr,
-                                                           int32_t* __restrict__ idx_out, T* __restrict__ zq_out,
-                                                           int32_t* __restrict__ counts_fix) {
-  // requires d % 4 == 0: rows are 16-byte aligned (pitch d + 4 floats -> conflict-free ds_read_b128 across lanes)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pitch = d + 4, d4 = d >> 2;
-  float* et = reinterpret_cast<float*>(smem);               // [K][pitch]
-  float* zrow = et + (size_t)K * pitch + (size_t)wave * d;  // [VQ_FIXL_WAVES][d]
-  const int namb = hdr->namb;
-  if ((int)blockIdx.x * VQ_FIXL_WAVES >= namb) return;                  // whole workgroup has no rows: skip the fill
-  {
-    // coalesced fill with 8 independent 16-byte loads in flight per thread (one memory latency per 32 KB, not per 4 KB)
-    const f32x4* E4 = reinterpret_cast<const f32x4*>(E);
-    const int nv = K * d4;
-    for (int i0 = tid; i0 < nv; i0 += 64 * VQ_FIXL_WAVES * 8) {
-      f32x4 v[8];
+    if ((unsigned)bk >= (unsigned)K) bk = 0;                         // no candidate at all (NaN row): argmin of an all-NaN row is 0
+    if (valid) {
+      const float* er = E + (int64_t)bk * d + q * kc;
+      T* zo = zq_out + row * (int64_t)d + q * kc;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int i = i0 + u * 64 * VQ_FIXL_WAVES; v[u] = i < nv ? E4[i] : f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + u * 64 * VQ_FIXL_WAVES;
-        if (i < nv) {
-          const int kk = i / d4, j = (i - kk * d4) * 4;
-          *reinterpret_cast<f32x4*>(et + kk * pitch + j) = f32x4{to_f32(from_f32<T>(v[u][0])), to_f32(from_f32<T>(v[u][1])),
-                                                                 to_f32(from_f32<T>(v[u][2])), to_f32(from_f32<T>(v[u][3]))};
+      for (int s = 0; s < NF * FE; ++s) {
+        if (q * kc + s < d) {
+          const float ev = to_f32(from_f32<T>(er[s]));
+          zo[s] = from_f32<T>(ev);
+          const float df = lq_get<T, NF>(zr, s / FE, s % FE) - ev;
+          sq_acc = fmaf(df, df, sq_acc);
         }
       }
+      if (kc == 0) { idx_out[row] = bk; atomicAdd(&counts_fix[bk], 1); }
     }
   }
-  __syncthreads();
-  const int nwaves = gridDim.x * VQ_FIXL_WAVES;
-  const float slack = 2.f * (float)(d + 8) * 1.1920929e-7f;
-  for (int it = blockIdx.x * VQ_FIXL_WAVES + wave; it < namb; it += nwaves) {
-    const int64_t n = amb_list[it];
-    __builtin_amdgcn_wave_barrier();
-    for (int j = lane; j < d; j += 64) zrow[j] = to_f32(Z[n * (int64_t)d + j]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const f32x4* z4 = reinterpret_cast<const f32x4*>(zrow);
-    float m32 = 3.0e38f;
-    double best = 1.0e300;
-    int bestk = 0x7fffffff;
-    for (int k0 = 0; k0 < K; k0 += 64) {
-      const int k = k0 + lane;
-      const f32x4* e4 = reinterpret_cast<const f32x4*>(et + (size_t)(k < K ? k : K - 1) * pitch);
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll 4
-      for (int j = 0; j < d4; ++j) {
-        const f32x4 zv = z4[j], ev = e4[j];
-        const float a0 = zv[0] - ev[0], a1 = zv[1] - ev[1], a2 = zv[2] - ev[2], a3 = zv[3] - ev[3];
-        s0 = fmaf(a0, a0, s0); s1 = fmaf(a1, a1, s1); s2 = fmaf(a2, a2, s2); s3 = fmaf(a3, a3, s3);
-      }
-      float s = (s0 + s1) + (s2 + s3);
-      if (k >= K) s = 3.0e38f;
-      float cm = s;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) cm = fminf(cm, __shfl_xor(cm, off, 64));
-      m32 = fminf(m32, cm);
-      if (s <= m32 * (1.f + slack) + 1e-30f) {
-        const float* er = et + (size_t)k * pitch;
-        double sd = 0.0;
-        for (int j = 0; j < d; ++j) { const double df = (double)zrow[j] - (double)er[j]; sd += df * df; }
-        if (sd < best) { best = sd; bestk = k; }
-      }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const double ob = __shfl_xor(best, off, 64);
-      const int ok = __shfl_xor(bestk, off, 64);
-      if (ob < best || (ob == best && ok < bestk)) { best = ob; bestk = ok; }
-    }
-    float sq = 0.f;
-    const float* eb = et + (size_t)bestk * pitch;
-    for (int j = lane; j < d; j += 64) {
-      const float ev = eb[j];
-      zq_out[n * (int64_t)d + j] = from_f32<T>(ev);
-      const float df = zrow[j] - ev;
-      sq = fmaf(df, df, sq);
-    }
-    sq = wave_sum(sq);
-    if (lane == 0) {
-      idx_out[n] = bestk;
-      atomicAdd(&counts_fix[bestk], 1);
-      atomicAdd(&hdr->sq_fix, (double)sq);
-    }
-  }
+  const float ws_ = wave_sum(sq_acc);
+  if (lane == 0 && ws_ != 0.f) atomicAdd(&hdr->sq_fix, (double)ws_);
 }
 
 // histogram slabs -> counts (epilogue of the generic slab reduction)
@@ -1311,7 +1228,7 @@ static size_t vq_prep_bytes_max(int K) {
          (size_t)((K + 15) / 16 + 64) * 16 * 128 * 4;
 }
 
-struct VqLayout { size_t hdr, counts_fix, partial, amb, hist, prep, total; int grid; };
+struct VqLayout { size_t hdr, counts_fix, partial, amb, amb_lim, hist, prep, total; int grid; };
 static VqLayout vq_layout(int64_t N, int K, int d) {
   VqLayout L;
   L.grid = vq_grid(N, d);
@@ -1320,6 +1237,7 @@ static VqLayout vq_layout(int64_t N, int K, int d) {
   L.counts_fix = o; o += ((size_t)K * 4 + 255) / 256 * 256;       // [hdr, counts_fix / counts_acc] are zeroed every call
   L.partial = o; o += ((size_t)L.grid * 16 * 4 + 255) / 256 * 256;
   L.amb = o; o += ((size_t)N * 4 + 255) / 256 * 256;
+  L.amb_lim = o; o += ((size_t)N * 4 + 255) / 256 * 256;
   L.hist = o; o += ((size_t)L.grid * K * 4 + 255) / 256 * 256;
   L.prep = o; o += vq_prep_bytes_max(K);                           // prepared codebook of the one-call entry point
   L.total = o;
@@ -1388,25 +1306,12 @@ static int launch_vq(const void* z, const float* E, char* prep, int64_t N, int K
     auto kern = vq_assign_kernel<T, NF, NT_, NW_>;                                                                                 \
     if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
     FRL_LAUNCH_AS("vq_assign_kernel", kern, dim3(L.grid), dim3(64 * NW_), lds, st, (const T*)z, E, en, hdr, N, K, d, Kc, idx, (T*)zq, \
-                  (float*)(ws + L.partial), (int32_t*)(ws + L.hist), hdr, (int32_t*)(ws + L.amb), pk);                             \
+                  (float*)(ws + L.partial), (int32_t*)(ws + L.hist), hdr, (int32_t*)(ws + L.amb), (float*)(ws + L.amb_lim), pk);    \
   } while (0)
   if (nw == 8) VQ_GO(2, 8); else VQ_GO(4, 4);
 #undef VQ_GO
-  const size_t fix_lds = (size_t)4 * (d + 64 * (d + 1)) * sizeof(float);
-  {
-    auto fk = vq_fixup_kernel<T>;
-    if (fix_lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fix_lds));
-  }
-  const size_t res_lds = ((size_t)K * (d + 4) + VQ_FIXL_WAVES * (size_t)d) * sizeof(float);
-  if (res_lds <= 150 * 1024 && (d & 3) == 0) {
-    auto fk = vq_fixup_lds_kernel<T>;
-    if (res_lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds));
-    FRL_LAUNCH_AS("vq_fixup_lds_kernel", fk, dim3(256), dim3(64 * VQ_FIXL_WAVES), res_lds, st, (const T*)z, E, K, d, (const int32_t*)(ws + L.amb), hdr, idx, (T*)zq,
-               (int32_t*)(ws + L.counts_fix));
-  } else {
-    FRL_LAUNCH((vq_fixup_kernel<T>), dim3(VQ_FIX_WAVES / 4), dim3(256), fix_lds, st, (const T*)z, E, K, d,
-               (const int32_t*)(ws + L.amb), hdr, idx, (T*)zq, (int32_t*)(ws + L.counts_fix));
-  }
+  FRL_LAUNCH_AS("vq_fixup_tile_kernel", (vq_fixup_tile_kernel<T, NF>), dim3(VQ_FIX_WAVES / 4), dim3(256), 0, st, (const T*)z, E, en, pk, K, P.kpad, d,
+                (const int32_t*)(ws + L.amb), (const float*)(ws + L.amb_lim), hdr, idx, (T*)zq, (int32_t*)(ws + L.counts_fix));
   launch_slab_reduce<int32_t, HistEpi>((const int32_t*)(ws + L.hist), L.grid, K, HistEpi{(const int32_t*)(ws + L.counts_fix), counts}, st);
   FRL_LAUNCH(vq_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)(ws + L.partial), L.grid * nw, (const VqHeader*)hdr,
              (const int32_t*)counts, K, N, d, stats);
