@@ -92,6 +92,7 @@ def test_fused_two_layer_encoder_matches_float64_and_the_modular_path(B, H, W):
     g = torch.Generator().manual_seed(B * H + W)
     torch.manual_seed(B * H + W)                                    # (the constructor draws the convolution weights from the global generator)
     enc = Conv2DEncoder(64, [128, 64], num_groups=8)
+    enc.fuse_min_samples = 1                                        # (the production threshold keeps small batches on the modular kernels)
     with torch.no_grad():
         for prm in enc.parameters():
             if prm.dim() == 1:

@@ -133,6 +133,7 @@ class Conv2DEncoder(nn.Module):
         self.input_dropout.p = rate
 
     fuse = True        # the two-layer bf16 configuration runs as one launch per direction (csrc/enc_fused.hip) when nothing prevents it
+    fuse_min_samples = 96
 
     def _fused_layers(self, x: torch.Tensor):
         """(conv1, norm1, conv2, norm2) when the fused kernels apply to this call, else None."""
@@ -144,6 +145,8 @@ class Conv2DEncoder(nn.Module):
         if self.training and (self.input_dropout.p > 0 or any(isinstance(m, _Marker) and m.kind == "dropout2d" and m.p > 0 for m in mods)):
             return None
         if any(c.bias is not None for c in convs) or norms[0].eps != norms[1].eps:
+            return None
+        if x.shape[0] < self.fuse_min_samples:                     # one workgroup per sample: a small batch would leave most CUs idle
             return None
         hw = x.numel() // (x.shape[0] * x.shape[-1])
         if not ops.encoder2_supported(convs[0].weight.shape[1], convs[0].weight.shape[0], convs[1].weight.shape[0], norms[0].num_groups,
