@@ -126,23 +126,25 @@ __device__ __forceinline__ void vq_exact_pair(const T* __restrict__ Z, const flo
   d1 = s1;
 }
 
-// Multi-chunk assignment (codebook image larger than one LDS chunk): ambiguous rows go to a global list for the vq_fixup kernels,
-// histograms to per-workgroup slabs.  A codebook that fits one chunk takes vq_assign_resident_kernel below.
+// Multi-chunk assignment (codebook image larger than one LDS chunk: K = 8192, d = 128 of BASELINE configs[3]).  The packed image is
+// streamed through TWO LDS chunk buffers by LDS-DMA (global_load_lds_dwordx4: the image is contiguous, no registers involved): chunk
+// i + 1 arrives while chunk i is scored, one barrier per chunk, the chunk sequence runs on across the workgroup's batches.  Keys are the
+// float-ordered ones of the resident kernel (no batch bias, per-row threshold), flagged rows go to a global list with their limits
+// (vq_fixup_tile_kernel), the histogram to integer atomics on the zeroed accumulator.
 template <typename T, int NF, int NT, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
-    const T* __restrict__ Z, const float* __restrict__ E, const float* __restrict__ en_g, const VqHeader* __restrict__ hdr,
-    int64_t N, int K, int d, int Kc, int32_t* __restrict__ idx_out, T* __restrict__ zq_out,
-    float* __restrict__ partial /*[grid*NW]*/, int32_t* __restrict__ hist_slab /*[grid][K]*/, VqHeader* __restrict__ hdr_w,
-    int32_t* __restrict__ amb_list, float* __restrict__ amb_lim, const typename DT<T>::frag_t* __restrict__ pk) {
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void vq_assign_kernel(
+    const T* __restrict__ Z, const float* __restrict__ E, const float* __restrict__ en_g, int64_t N, int K, int d, int Kc,
+    int32_t* __restrict__ idx_out, T* __restrict__ zq_out, float* __restrict__ partial /*[grid*NW]*/, int32_t* __restrict__ counts_acc,
+    VqHeader* __restrict__ hdr_w, int32_t* __restrict__ amb_list, float* __restrict__ amb_lim, const typename DT<T>::frag_t* __restrict__ pk) {
   typedef typename DT<T>::frag_t frag_t;
   constexpr int FE = DT<T>::FE;
   constexpr int q = NF * FE;                 // channels per lane quarter
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  frag_t* wl = reinterpret_cast<frag_t*>(smem);                       // [Kc/16][NF][64]
-  float* enl = reinterpret_cast<float*>(smem + (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t));  // [Kc]
-  int* hist = reinterpret_cast<int*>(enl + Kc);                        // [K]
-  unsigned* cbw = reinterpret_cast<unsigned*>(hist + K);               // batch maximum of ||z||^2 (f32 bits), [NW + 1] (+ pad to 32)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk_bytes = (Kc / 16) * NF * 64 * (int)sizeof(frag_t);  // a multiple of 1 KB
+  const int buf_bytes = chunk_bytes + Kc * 4;                         // fragments | ||e||^2 of the chunk
+  float* cbw = reinterpret_cast<float*>(smem + 2 * buf_bytes);         // [NW] scratch of the prologue
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int vx = lane & 15, kc = lane >> 4;
   const int nchunks = (K + Kc - 1) / Kc;
   const bool fast = (d == 4 * q);
@@ -152,35 +154,60 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
     for (int k = tid; k < K; k += NW * 64) m = fmaxf(m, en_g[k]);
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if (lane == 0) cbw[wave] = __float_as_uint(m);
+    if (lane == 0) cbw[wave] = m;
     __syncthreads();
-    unsigned mm = 0u;
+    float mm = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) mm = mm > cbw[w] ? mm : cbw[w];
-    enmax = __uint_as_float(mm);
-    __syncthreads();
+    for (int w = 0; w < NW; ++w) mm = fmaxf(mm, cbw[w]);
+    enmax = mm;
   }
   const float err_rel = (float)(4 * q + 8) * 1.1920929e-7f;            // (d_pad+8) * 2^-23: f32 accumulation of exact products
-  const float thr_rel = 3.0517578125e-5f + 2.f * err_rel;              // 2^-(22-7) key truncation of both scores + 2*err
-
-  for (int k = tid; k < K; k += NW * 64) hist[k] = 0;
+  const float thr_rel = (3.0517578125e-5f + 2.f * err_rel) * 1.001953125f;   // 2^-15: key truncation of both scores, + 2*err, + margin
+  const float enroot = sqrtf(enmax);
   float sq_acc = 0.f;
-  int filled_chunk = -1;
+
+  // chunk c of the image (fragments, then its norms) into buffer `buf`: 1 KB pieces dealt round-robin to the waves
+  const int npiece = chunk_bytes >> 10;
+  auto dma_chunk = [&](int c, int buf) {
+    const char* src = reinterpret_cast<const char*>(pk) + (size_t)c * chunk_bytes;
+    int lane_ = lane;
+    asm volatile("" : "+v"(lane_));
+    for (int p = wave; p < npiece; p += NW) {                      // (wave-uniform trip count)
+      const char* sp = src + p * 1024 + lane_ * 16;
+      const int ldst = buf * buf_bytes + p * 1024;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(sp), "s"(ldst) : "memory");
+    }
+    for (int p = wave; p < (Kc >> 6); p += NW) {                   // the chunk's norms, 64 floats per piece (en_g holds kpad entries: 3e38 beyond K)
+      const float* sp = en_g + c * Kc + p * 64 + lane_;
+      const int ldst = buf * buf_bytes + chunk_bytes + p * 256;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(sp), "s"(ldst) : "memory");
+    }
+  };
 
   const int64_t vec_per_batch = NW * NT * 16;
   const int64_t nbatch = (N + vec_per_batch - 1) / vec_per_batch;
+  const int64_t my_batches = (int64_t)blockIdx.x < nbatch ? (nbatch - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const int64_t total_it = my_batches * nchunks;                  // chunk iterations of this workgroup, across its batches
+  int64_t it = 0;
+  if (total_it > 0) dma_chunk(0, 0);
   for (int64_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
     const int64_t v0 = (batch * NW + wave) * (NT * 16);
     LQTile<T, NF> zt[NT];
     float thr[NT];
     unsigned g1[NT], g2[NT];
     int gc[NT];
-    float zmax = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       int64_t row = v0 + t * 16 + vx;
       if (row >= N) row = N - 1;
       lq_load<T, NF>(zt[t], Z, row, d, kc, fast);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
       float zn = 0.f;
 #pragma unroll
       for (int s = 0; s < NF; ++s)
@@ -188,44 +215,24 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
         for (int e = 0; e < FE; ++e) { const float v = lq_get<T, NF>(zt[t], s, e); zn = fmaf(v, v, zn); }
       zn += __shfl_xor(zn, 16, 64);
       zn += __shfl_xor(zn, 32, 64);
-      zmax = fmaxf(zmax, zn);
-      g1[t] = 0xFFFFFFFFu; g2[t] = 0xFFFFFFFFu; gc[t] = 0;
-    }
-    // One positive bias per workgroup batch (max ||z||^2 of its 256 vectors, + margin) is folded into the LDS copy of
-    // ||e||^2, so the MFMA accumulator is initialised straight from LDS and every score en + Cb - 2 z.e stays > 0.
+      const float sroot = sqrtf(zn) + enroot;                      // |score| and every partial sum <= (||z|| + ||e||max)^2
+      thr[t] = sroot * sroot * thr_rel + 1e-37f;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, off, 64));
-    __syncthreads();                                             // previous batch is done with enl / the slots
-    if (lane == 0) cbw[wave] = __float_as_uint(zmax);
-    __syncthreads();
-    {
-      unsigned m = 0u;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) m = m > cbw[w] ? m : cbw[w];
-      cbw[NW] = m;                                               // same value from every thread (benign)
+      for (int s = 0; s < NF; ++s) asm volatile("" : "+v"(zt[t].f[s]));   // (else the unpacked floats stay live through the chunk loop)
+      g1[t] = 0x7F800000u; g2[t] = 0x7F800000u; gc[t] = 0;         // +inf
     }
-    const float zbm = __uint_as_float(cbw[NW]);
-    const float Cb = zbm + 9.765625e-4f * (zbm + enmax) + 1e-30f;     // + 2^-10 (zmax + enmax)
-    {
-      const float sroot = sqrtf(zbm) + sqrtf(enmax);
-      const float tv = (sroot * sroot + Cb) * thr_rel;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) thr[t] = tv;
-    }
-    for (int c = 0; c < nchunks; ++c) {
-      {
-        __syncthreads();
-        const int kbase = c * Kc;
-        if (filled_chunk != c) copy_frags_lds<T>(wl, pk + (size_t)(kbase / 16) * NF * 64, (Kc / 16) * NF * 64, tid, NW * 64);
-        for (int i = tid; i < Kc; i += NW * 64) enl[i] = (kbase + i < K) ? en_g[kbase + i] + Cb : 3.0e38f;
-        __syncthreads();
-        filled_chunk = c;
-      }
+    for (int c = 0; c < nchunks; ++c, ++it) {
+      const int buf = (int)(it & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of chunk `it` (and its norm loads) have landed
+      __syncthreads();                                           // ... everybody's; everybody is done with the other buffer
+      if (it + 1 < total_it) dma_chunk((c + 1 == nchunks) ? 0 : c + 1, buf ^ 1);
+      const frag_t* wl = reinterpret_cast<const frag_t*>(smem + buf * buf_bytes);
+      const float* enl = reinterpret_cast<const float*>(smem + buf * buf_bytes + chunk_bytes);
       const int nmb = Kc / 16;
       for (int g0 = 0; g0 < nmb; g0 += 8) {
         unsigned c1[NT], c2[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { c1[t] = 0xFFFFFFFFu; c2[t] = 0xFFFFFFFFu; }
+        for (int t = 0; t < NT; ++t) { c1[t] = 0x7F800000u; c2[t] = 0x7F800000u; }
         const int g1e = (g0 + 8) < nmb ? (g0 + 8) : nmb;
         for (int mb = g0; mb < g1e; ++mb) {
           const f32x4 en4 = *reinterpret_cast<const f32x4*>(enl + mb * 16 + 4 * kc);
@@ -241,47 +248,44 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const unsigned key = (__float_as_uint(acc[r]) & ~VQ_IDX_MASK) | (lidx + r);
-              asm("v_med3_u32 %0, %1, %2, %3" : "=v"(c2[t]) : "v"(c1[t]), "v"(c2[t]), "v"(key));   // runner-up (c1 <= c2)
-              c1[t] = c1[t] < key ? c1[t] : key;
+              asm("v_med3_f32 %0, %1, %2, %3" : "=v"(c2[t]) : "v"(c1[t]), "v"(c2[t]), "v"(key));   // runner-up (c1 <= c2)
+              asm("v_min_f32 %0, %1, %2" : "=v"(c1[t]) : "v"(c1[t]), "v"(key));
             }
           }
         }
         const int gid = c * (Kc / 16) + g0;                     // group base in units of 16 codes
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const unsigned hi = g1[t] > c1[t] ? g1[t] : c1[t];
-          const unsigned lo2 = g2[t] < c2[t] ? g2[t] : c2[t];
-          g2[t] = hi < lo2 ? hi : lo2;
-          if (c1[t] < g1[t]) { g1[t] = c1[t]; gc[t] = gid; }
+          const float a1 = __uint_as_float(g1[t]), a2 = __uint_as_float(g2[t]), b1 = __uint_as_float(c1[t]), b2 = __uint_as_float(c2[t]);
+          const float hi = fmaxf(a1, b1), lo2 = fminf(a2, b2);
+          g2[t] = __float_as_uint(fminf(hi, lo2));
+          if (b1 < a1) { g1[t] = c1[t]; gc[t] = gid; }
         }
       }
     }
-    // ---- wave-level min-reduce over the 4 lane groups that share a vector ----
+    // ---- min-reduce over the 4 lane groups that share a row; ambiguity test; z_q, squared error, histogram of the settled rows ----
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
       for (int off = 16; off <= 32; off <<= 1) {
         const unsigned o1 = __shfl_xor(g1[t], off, 64), o2 = __shfl_xor(g2[t], off, 64);
         const int oc = __shfl_xor(gc[t], off, 64);
-        const unsigned hi = g1[t] > o1 ? g1[t] : o1;
-        const unsigned lo2 = g2[t] < o2 ? g2[t] : o2;
-        g2[t] = hi < lo2 ? hi : lo2;
-        // deterministic tie rule between lane groups: smaller (key, chunk) wins
-        if (o1 < g1[t] || (o1 == g1[t] && oc < gc[t])) { g1[t] = o1; gc[t] = oc; }
+        const float a1 = __uint_as_float(g1[t]), a2 = __uint_as_float(g2[t]), b1 = __uint_as_float(o1), b2 = __uint_as_float(o2);
+        const float hi = fmaxf(a1, b1), lo2 = fminf(a2, b2);
+        g2[t] = __float_as_uint(fminf(hi, lo2));
+        if (b1 < a1 || (b1 == a1 && (oc < gc[t] || (oc == gc[t] && o1 < g1[t])))) { g1[t] = o1; gc[t] = oc; }
       }
       const int64_t row = v0 + t * 16 + vx;
       const int code = gc[t] * 16 + (int)(g1[t] & VQ_IDX_MASK);
       const float s1 = __uint_as_float(g1[t] & ~VQ_IDX_MASK), s2 = __uint_as_float(g2[t] & ~VQ_IDX_MASK);
-      const bool amb = !((s2 - s1) > thr[t]);   // also catches NaN
+      const bool amb = !((s2 - s1) > thr[t]) || (unsigned)code >= (unsigned)K;   // also catches NaN / inf rows
       if (row < N) {
         if (kc == 0) {
-          idx_out[row] = amb ? (-1 - code) : code;
+          idx_out[row] = amb ? 0 : code;
           if (amb) {
             const int pos = atomicAdd(&hdr_w->namb, 1);
             amb_list[pos] = (int32_t)row;
-            // every code whose bias-free f32 score is <= lim may be the float64 arg-min: s1 carries the batch bias Cb, thr bounds the key
-            // truncation and the rounding of both passes
-            amb_lim[pos] = (s1 - Cb) + thr[t] + 2.3841858e-7f * (s1 + Cb);
+            amb_lim[pos] = s1 + thr[t] + 2.3841858e-7f * fabsf(s1);   // every code whose f32 score is <= this may be the float64 arg-min
           }
         }
         if (!amb) {
@@ -312,16 +316,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_kernel(
               }
             }
           }
-          if (kc == 0) atomicAdd(&hist[code], 1);
+          if (kc == 0) atomicAdd(&counts_acc[code], 1);          // integer sums: order-independent, bit-reproducible
         }
       }
     }
   }
-  // ---- per-workgroup outputs: wave partials of the squared error, histogram ----
+  // ---- per-workgroup output: wave partials of the squared error ----
   const float ws_ = wave_sum(sq_acc);
   if (lane == 0) partial[blockIdx.x * NW + wave] = ws_;
-  __syncthreads();
-  for (int k = tid; k < K; k += NW * 64) hist_slab[(int64_t)blockIdx.x * K + k] = hist[k];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -782,27 +784,32 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_resident
 }
 
 // ---------------------------------------------------------------------------------------------
-// Exact re-evaluation of the flagged rows of the multi-chunk path, 16 rows per wave: the rows are re-scored against the WHOLE packed
+// Exact re-evaluation of the flagged rows of the multi-chunk path, 16 rows per workgroup (8 waves, each with its share of the code
+// blocks, merged in wave order): the rows are re-scored against the WHOLE packed
 // image on the matrix cores (fragments streamed from L2: 2 MB per tile at K = 8192, d = 128, instead of the 4 MB float32 codebook per
 // ROW of the former one-wave-per-row kernels -- 17 ms at 1 % flagged rows), codes under the row's limit are evaluated in float64
 // in-lane (up to two pending per lane, flushed together), first index wins ties.  Row results do not depend on the list order; the
 // squared-error sum uses a float64 atomic, the histogram integer atomics.
 // ---------------------------------------------------------------------------------------------
+#define VQ_FIXT_WAVES 8      // waves per tile of 16 flagged rows: each scores its share of the code blocks
 template <typename T, int NF>
-__global__ __launch_bounds__(256) void vq_fixup_tile_kernel(const T* __restrict__ Z, const float* __restrict__ E, const float* __restrict__ en_g,
+__global__ __launch_bounds__(64 * VQ_FIXT_WAVES) void vq_fixup_tile_kernel(const T* __restrict__ Z, const float* __restrict__ E, const float* __restrict__ en_g,
                                                             const typename DT<T>::frag_t* __restrict__ pk, int K, int kpad, int d,
                                                             const int32_t* __restrict__ amb_list, const float* __restrict__ amb_lim,
                                                             VqHeader* __restrict__ hdr, int32_t* __restrict__ idx_out, T* __restrict__ zq_out,
                                                             int32_t* __restrict__ counts_fix) {
   constexpr int FE = DT<T>::FE;
   constexpr int q = NF * FE;
+  __shared__ double mrg_d[VQ_FIXT_WAVES][16];
+  __shared__ int mrg_k[VQ_FIXT_WAVES][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int vx = lane & 15, kc = lane >> 4;
   const bool fast = (d == 4 * q);
   const int namb = hdr->namb;
-  const int ntile = (namb + 15) >> 4, nwaves = gridDim.x * 4, nmb = kpad >> 4;
+  const int ntile = (namb + 15) >> 4, nmb = kpad >> 4;
+  const int mb0 = (wave * nmb) / VQ_FIXT_WAVES, mb1 = ((wave + 1) * nmb) / VQ_FIXT_WAVES;
   float sq_acc = 0.f;
-  for (int tile = blockIdx.x * 4 + wave; tile < ntile; tile += nwaves) {
+  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const int li = tile * 16 + vx;
     const bool valid = li < namb;
     const int64_t row = amb_list[valid ? li : tile * 16];
@@ -821,7 +828,7 @@ __global__ __launch_bounds__(256) void vq_fixup_tile_kernel(const T* __restrict_
       p0 = p1 = -1;
     };
 #pragma unroll 2
-    for (int mb = 0; mb < nmb; ++mb) {
+    for (int mb = mb0; mb < mb1; ++mb) {
       f32x4 acc = *reinterpret_cast<const f32x4*>(en_g + mb * 16 + 4 * kc);
 #pragma unroll
       for (int s = 0; s < NF; ++s) acc = mfma16(pk[(size_t)(mb * NF + s) * 64 + lane], zr.f[s], acc);
@@ -840,35 +847,45 @@ __global__ __launch_bounds__(256) void vq_fixup_tile_kernel(const T* __restrict_
       const int okk = __shfl_xor(bk, off, 64);
       if (ob < bestd || (ob == bestd && okk < bk)) { bestd = ob; bk = okk; }
     }
-    if ((unsigned)bk >= (unsigned)K) bk = 0;                         // no candidate at all (NaN row): argmin of an all-NaN row is 0
-    if (valid) {
-      const float* er = E + (int64_t)bk * d + q * kc;
-      T* zo = zq_out + row * (int64_t)d + q * kc;
+    // the waves' shares are merged in wave order: smallest distance, then smallest code (= first index over the whole codebook)
+    if (kc == 0) { mrg_d[wave][vx] = bestd; mrg_k[wave][vx] = bk; }
+    __syncthreads();
+    if (wave == 0) {
+      bestd = mrg_d[0][vx]; bk = mrg_k[0][vx];
 #pragma unroll
-      for (int s = 0; s < NF * FE; ++s) {
-        if (q * kc + s < d) {
-          const float ev = to_f32(from_f32<T>(er[s]));
-          zo[s] = from_f32<T>(ev);
-          const float df = lq_get<T, NF>(zr, s / FE, s % FE) - ev;
-          sq_acc = fmaf(df, df, sq_acc);
-        }
+      for (int w = 1; w < VQ_FIXT_WAVES; ++w) {
+        const double ob = mrg_d[w][vx];
+        const int okk = mrg_k[w][vx];
+        if (ob < bestd || (ob == bestd && okk < bk)) { bestd = ob; bk = okk; }
       }
-      if (kc == 0) { idx_out[row] = bk; atomicAdd(&counts_fix[bk], 1); }
+      if ((unsigned)bk >= (unsigned)K) bk = 0;                       // no candidate at all (NaN row): argmin of an all-NaN row is 0
+      if (valid) {
+        const float* er = E + (int64_t)bk * d + q * kc;
+        T* zo = zq_out + row * (int64_t)d + q * kc;
+#pragma unroll
+        for (int s = 0; s < NF * FE; ++s) {
+          if (q * kc + s < d) {
+            const float ev = to_f32(from_f32<T>(er[s]));
+            zo[s] = from_f32<T>(ev);
+            const float df = lq_get<T, NF>(zr, s / FE, s % FE) - ev;
+            sq_acc = fmaf(df, df, sq_acc);
+          }
+        }
+        if (kc == 0) { idx_out[row] = bk; atomicAdd(&counts_fix[bk], 1); }
+      }
     }
+    __syncthreads();
   }
-  const float ws_ = wave_sum(sq_acc);
-  if (lane == 0 && ws_ != 0.f) atomicAdd(&hdr->sq_fix, (double)ws_);
+  if (wave == 0) {
+    const float ws_ = wave_sum(sq_acc);
+    if (lane == 0 && ws_ != 0.f) atomicAdd(&hdr->sq_fix, (double)ws_);
+  }
 }
-
-// histogram slabs -> counts (epilogue of the generic slab reduction)
-struct HistEpi {
-  const int32_t* counts_fix; int32_t* counts_out;
-  __device__ void operator()(int64_t i, int s) const { counts_out[i] = s + counts_fix[i]; }
-};
 
 // stats = {sqerr_sum, perplexity, n_re-evaluated, 0}
 __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restrict__ partial, int npartial, const VqHeader* __restrict__ hdr,
-                                                          const int32_t* __restrict__ counts, int K, int64_t N, int d, float* __restrict__ stats) {
+                                                          const int32_t* __restrict__ counts_acc, int32_t* __restrict__ counts, int K, int64_t N,
+                                                          int d, float* __restrict__ stats) {
   __shared__ double red[256];
   double s = 0.0;
   for (int i = threadIdx.x; i < npartial; i += 256) s += (double)partial[i];
@@ -879,7 +896,9 @@ __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restric
   __syncthreads();
   double h = 0.0;
   for (int k = threadIdx.x; k < K; k += 256) {
-    const double p = (double)counts[k] / (double)N;
+    const int cnt = counts_acc[k];
+    counts[k] = cnt;
+    const double p = (double)cnt / (double)N;
     h += p * log(p + 1e-10);
   }
   red[threadIdx.x] = h;
@@ -1228,7 +1247,7 @@ static size_t vq_prep_bytes_max(int K) {
          (size_t)((K + 15) / 16 + 64) * 16 * 128 * 4;
 }
 
-struct VqLayout { size_t hdr, counts_fix, partial, amb, amb_lim, hist, prep, total; int grid; };
+struct VqLayout { size_t hdr, counts_fix, partial, amb, amb_lim, prep, total; int grid; };
 static VqLayout vq_layout(int64_t N, int K, int d) {
   VqLayout L;
   L.grid = vq_grid(N, d);
@@ -1238,7 +1257,6 @@ static VqLayout vq_layout(int64_t N, int K, int d) {
   L.partial = o; o += ((size_t)L.grid * 16 * 4 + 255) / 256 * 256;
   L.amb = o; o += ((size_t)N * 4 + 255) / 256 * 256;
   L.amb_lim = o; o += ((size_t)N * 4 + 255) / 256 * 256;
-  L.hist = o; o += ((size_t)L.grid * K * 4 + 255) / 256 * 256;
   L.prep = o; o += vq_prep_bytes_max(K);                           // prepared codebook of the one-call entry point
   L.total = o;
   return L;
@@ -1299,22 +1317,23 @@ static int launch_vq(const void* z, const float* E, char* prep, int64_t N, int K
 #undef VQ_GO
     return frl_check_launch("vq_assign");
   }
-  size_t lds = (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc * 4 + (size_t)K * 4 + 128;
-  if (lds > 160 * 1024) return frl_fail(-3, "vq_assign: LDS budget exceeded (K too large for histogram)");
+  // multi-chunk: two half-size chunk buffers (fragments + norms each), so that two workgroups still fit a CU
+  const int Kc2 = Kc >= 32 ? Kc / 2 : Kc;
+  const size_t lds = 2 * ((size_t)(Kc2 / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc2 * 4) + 64;
+  if (((Kc2 / 16) * NF * 64 * sizeof(frag_t)) % 1024 != 0 || (Kc2 & 63) != 0) return frl_fail(-3, "vq_assign: chunk is not a whole number of DMA pieces");
 #define VQ_GO(NT_, NW_)                                                                                                            \
   do {                                                                                                                             \
     auto kern = vq_assign_kernel<T, NF, NT_, NW_>;                                                                                 \
     if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
-    FRL_LAUNCH_AS("vq_assign_kernel", kern, dim3(L.grid), dim3(64 * NW_), lds, st, (const T*)z, E, en, hdr, N, K, d, Kc, idx, (T*)zq, \
-                  (float*)(ws + L.partial), (int32_t*)(ws + L.hist), hdr, (int32_t*)(ws + L.amb), (float*)(ws + L.amb_lim), pk);    \
+    FRL_LAUNCH_AS("vq_assign_kernel", kern, dim3(L.grid), dim3(64 * NW_), lds, st, (const T*)z, E, en, N, K, d, Kc2, idx, (T*)zq,   \
+                  (float*)(ws + L.partial), (int32_t*)(ws + L.counts_fix), hdr, (int32_t*)(ws + L.amb), (float*)(ws + L.amb_lim), pk); \
   } while (0)
   if (nw == 8) VQ_GO(2, 8); else VQ_GO(4, 4);
 #undef VQ_GO
-  FRL_LAUNCH_AS("vq_fixup_tile_kernel", (vq_fixup_tile_kernel<T, NF>), dim3(VQ_FIX_WAVES / 4), dim3(256), 0, st, (const T*)z, E, en, pk, K, P.kpad, d,
+  FRL_LAUNCH_AS("vq_fixup_tile_kernel", (vq_fixup_tile_kernel<T, NF>), dim3(1024), dim3(64 * VQ_FIXT_WAVES), 0, st, (const T*)z, E, en, pk, K, P.kpad, d,
                 (const int32_t*)(ws + L.amb), (const float*)(ws + L.amb_lim), hdr, idx, (T*)zq, (int32_t*)(ws + L.counts_fix));
-  launch_slab_reduce<int32_t, HistEpi>((const int32_t*)(ws + L.hist), L.grid, K, HistEpi{(const int32_t*)(ws + L.counts_fix), counts}, st);
   FRL_LAUNCH(vq_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)(ws + L.partial), L.grid * nw, (const VqHeader*)hdr,
-             (const int32_t*)counts, K, N, d, stats);
+             (const int32_t*)(ws + L.counts_fix), counts, K, N, d, stats);
   return frl_check_launch("vq_assign");
 }
 
