@@ -143,6 +143,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void vq_assign_kernel(
   const int chunk_bytes = (Kc / 16) * NF * 64 * (int)sizeof(frag_t);  // a multiple of 1 KB
   const int buf_bytes = chunk_bytes + Kc * 4;                         // fragments | ||e||^2 of the chunk
   float* cbw = reinterpret_cast<float*>(smem + 2 * buf_bytes);         // [NW] scratch of the prologue
+  // histogram: small codebooks are hit by many rows per code, so the workgroup counts in LDS and adds each used code once at the end;
+  // large ones (K > 2048: few rows per code, 32 KB of LDS) go straight to the global integer atomics
+  int* hist = reinterpret_cast<int*>(smem + 2 * buf_bytes + 64);
+  const bool lds_hist = K <= 2048;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int vx = lane & 15, kc = lane >> 4;
@@ -165,6 +169,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void vq_assign_kernel(
   const float thr_rel = (3.0517578125e-5f + 2.f * err_rel) * 1.001953125f;   // 2^-15: key truncation of both scores, + 2*err, + margin
   const float enroot = sqrtf(enmax);
   float sq_acc = 0.f;
+  if (lds_hist)
+    for (int k = tid; k < K; k += NW * 64) hist[k] = 0;            // (visible behind the first chunk barrier)
 
   // chunk c of the image (fragments, then its norms) into buffer `buf`: 1 KB pieces dealt round-robin to the waves
   const int npiece = chunk_bytes >> 10;
@@ -316,14 +322,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void vq_assign_kernel(
               }
             }
           }
-          if (kc == 0) atomicAdd(&counts_acc[code], 1);          // integer sums: order-independent, bit-reproducible
+          if (kc == 0) atomicAdd(lds_hist ? &hist[code] : &counts_acc[code], 1);   // integer sums: order-independent, bit-reproducible
         }
       }
     }
   }
-  // ---- per-workgroup output: wave partials of the squared error ----
+  // ---- per-workgroup output: wave partials of the squared error; LDS histogram -> one global add per used code ----
   const float ws_ = wave_sum(sq_acc);
   if (lane == 0) partial[blockIdx.x * NW + wave] = ws_;
+  if (lds_hist) {
+    __syncthreads();
+    for (int k = tid; k < K; k += NW * 64) {
+      const int h = hist[k];
+      if (h) atomicAdd(&counts_acc[k], h);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1319,7 +1332,7 @@ static int launch_vq(const void* z, const float* E, char* prep, int64_t N, int K
   }
   // multi-chunk: two half-size chunk buffers (fragments + norms each), so that two workgroups still fit a CU
   const int Kc2 = Kc >= 32 ? Kc / 2 : Kc;
-  const size_t lds = 2 * ((size_t)(Kc2 / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc2 * 4) + 64;
+  const size_t lds = 2 * ((size_t)(Kc2 / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc2 * 4) + 64 + (K <= 2048 ? (size_t)K * 4 : 0);
   if (((Kc2 / 16) * NF * 64 * sizeof(frag_t)) % 1024 != 0 || (Kc2 & 63) != 0) return frl_fail(-3, "vq_assign: chunk is not a whole number of DMA pieces");
 #define VQ_GO(NT_, NW_)                                                                                                            \
   do {                                                                                                                             \
