@@ -1006,16 +1006,17 @@ __global__ __launch_bounds__(256) void vq_bwd_kernel(const T* __restrict__ gout,
 // The one-hot A fragments are generated in registers from the staged indices (exact 0/1 in bf16), the z tile is fetched
 // k-strided with ds_read_b64_tr_b16, products are exact and accumulated in f32 in a fixed order -> bit-reproducible,
 // no LDS float atomics.  g_z = g_out + cz (z - e_idx) is fused on the staged tile.
-// Each wave owns RB row blocks (16 codes each) x CB column blocks (16 channels) of the [Kc x d] chunk; chunks of the
+// Each of the NWV = 8 waves (two per SIMD: LDS and matrix-pipe latencies of one hide behind the other) owns RB row blocks (16 codes
+// each) x CB column blocks (16 channels) of the [Kc x d] chunk; chunks of the
 // codebook are an outer loop (z is re-read once per chunk; one chunk covers K <= 512 at d <= 64).
 // ---------------------------------------------------------------------------------------------
-template <int RB, int CB>
-__global__ __launch_bounds__(256) void vq_bwd_mfma_kernel(const bf16* __restrict__ gout, const bf16* __restrict__ Z, const bf16* __restrict__ ZQ,
+template <int RB, int CB, int NWV>
+__global__ __launch_bounds__(64 * NWV) void vq_bwd_mfma_kernel(const bf16* __restrict__ gout, const bf16* __restrict__ Z, const bf16* __restrict__ ZQ,
                                                           const float* __restrict__ E,
                                                           const int32_t* __restrict__ idx, const float* __restrict__ gscale, float cz_base,
                                                           int64_t N, int K, int d, int64_t rows_per_wg, bf16* __restrict__ gz,
                                                           float* __restrict__ slab /*[grid][K][d]*/) {
-  constexpr int DP = CB * 16, PITCH = DP + 8, KC = RB * 4 * 16;
+  constexpr int DP = CB * 16, PITCH = DP + 8, KC = RB * NWV * 16, NTH = 64 * NWV;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* zt = reinterpret_cast<bf16*>(smem);                      // [64][PITCH]
   int* it = reinterpret_cast<int*>(zt + 64 * PITCH);             // [64]
@@ -1036,14 +1037,14 @@ __global__ __launch_bounds__(256) void vq_bwd_mfma_kernel(const bf16* __restrict
       for (int b = 0; b < CB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     // register image of the NEXT 64-row tile (16-byte channel vectors): z, and on the first chunk g_out and z_q for the fused
     // g_z = g_out + cz (z - z_q); requested behind the MFMAs of the current tile
-    constexpr int NV = (64 * (DP / 8) + 255) / 256;
+    constexpr int NV = (64 * (DP / 8) + NTH - 1) / NTH;
     const bool pre = fast && (ZQ != nullptr || gz == nullptr || kbase != 0);      // prefetch path: no codebook gather needed
     const bool want_gz = (kbase == 0 && gz != nullptr);
     bf16x8 rz[NV], rg[NV], rq[NV];
     auto fetch = [&](int64_t p0) {
 #pragma unroll
       for (int u = 0; u < NV; ++u) {
-        const int i = tid + u * 256;
+        const int i = tid + u * NTH;
         const int row = i / vpr, c0 = (i % vpr) * 8;
         const int64_t n = p0 + row;
         const bool ok = i < 64 * vpr && n < r1 && c0 < d;
@@ -1063,7 +1064,7 @@ __global__ __launch_bounds__(256) void vq_bwd_mfma_kernel(const bf16* __restrict
       if (pre) {
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
-          const int i = tid + u * 256;
+          const int i = tid + u * NTH;
           if (i >= 64 * vpr) continue;
           const int row = i / vpr, c0 = (i % vpr) * 8;
           const int64_t n = p0 + row;
@@ -1077,7 +1078,7 @@ __global__ __launch_bounds__(256) void vq_bwd_mfma_kernel(const bf16* __restrict
         }
       } else {
       // stage 64 rows of z (zero padded) and their indices; first chunk also writes g_z
-      for (int i = tid; i < 64 * vpr; i += 256) {
+      for (int i = tid; i < 64 * vpr; i += NTH) {
         const int row = i / vpr, c0 = (i % vpr) * 8;
         const int64_t n = p0 + row;
         float zv[8];
@@ -1466,13 +1467,13 @@ int frl_vq_bwd(const void* g_out, const void* z, const void* zq, const float* E,
   } else if (dtype == FRL_BF16) {
     const int64_t rows64 = (rows + 63) / 64 * 64;
     if (d <= 32) {
-      FRL_LAUNCH((vq_bwd_mfma_kernel<8, 2>), dim3(VQ_BWD_WGS), dim3(256), (size_t)64 * 40 * 2 + 256, stream, (const bf16*)g_out, (const bf16*)z, (const bf16*)zq, E, idx,
+      FRL_LAUNCH((vq_bwd_mfma_kernel<4, 2, 8>), dim3(VQ_BWD_WGS), dim3(512), (size_t)64 * 40 * 2 + 256, stream, (const bf16*)g_out, (const bf16*)z, (const bf16*)zq, E, idx,
                  gscale, cz, N, K, d, rows64, (bf16*)g_z_out, slab);
     } else if (d <= 64) {
-      FRL_LAUNCH((vq_bwd_mfma_kernel<8, 4>), dim3(VQ_BWD_WGS), dim3(256), (size_t)64 * 72 * 2 + 256, stream, (const bf16*)g_out, (const bf16*)z, (const bf16*)zq, E, idx,
+      FRL_LAUNCH((vq_bwd_mfma_kernel<4, 4, 8>), dim3(VQ_BWD_WGS), dim3(512), (size_t)64 * 72 * 2 + 256, stream, (const bf16*)g_out, (const bf16*)z, (const bf16*)zq, E, idx,
                  gscale, cz, N, K, d, rows64, (bf16*)g_z_out, slab);
     } else {
-      FRL_LAUNCH((vq_bwd_mfma_kernel<4, 8>), dim3(VQ_BWD_WGS), dim3(256), (size_t)64 * 136 * 2 + 256, stream, (const bf16*)g_out, (const bf16*)z, (const bf16*)zq, E, idx,
+      FRL_LAUNCH((vq_bwd_mfma_kernel<2, 8, 8>), dim3(VQ_BWD_WGS), dim3(512), (size_t)64 * 136 * 2 + 256, stream, (const bf16*)g_out, (const bf16*)z, (const bf16*)zq, E, idx,
                  gscale, cz, N, K, d, rows64, (bf16*)g_z_out, slab);
     }
     launch_slab_reduce<float, CodeEpi>((const float*)slab, VQ_BWD_WGS, (int64_t)K * d, CodeEpi{E, counts, gscale, ce, d, 1, g_E_out, sums_out}, stream);
