@@ -154,6 +154,23 @@ def test_three_step_loss_trajectory_matches_oracle(golden_dir):
     assert np.abs(np.asarray(traj) - fx["traj"]).max() < 2e-5, (traj, fx["traj"])
 
 
+def test_sixty_step_trajectory_matches_the_oracle_trainer(golden_dir):
+    """Longer than the committed 3-step fixture: the HIP trainer and the float64 oracle trainer run side by side for 60 optimiser
+    steps over a recycled pool of tiles.  Index flips would show as a jump in loss or perplexity; none is allowed."""
+    from frl_hip.training.trainer import VQVAETrainer
+    fx = _load(golden_dir, "vqvae_tiny_seed0")
+    tr = VQVAETrainer(_vqvae_from_fixture(fx), lr=1e-3, total_steps=60)
+    sd = {k[6:]: torch.from_numpy(fx[k]).double() for k in fx.files if k.startswith("state.")}
+    hp = dict(type_encoder_num_groups=4, phase_tcn_num_groups=4, phase_tcn_dilations=(1, 2, 4), beta=0.25)
+    otr = O.OracleTrainer(sd, hp, lr=1e-3, total_steps=60)
+    pool = torch.randn(4, 2, 5, 8, 8, 8, generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+    for i in range(60):
+        a = tr.step(pool[i % 4].float().to(DEV))
+        b = otr.step(pool[i % 4])
+        assert abs(a["loss"].item() - float(b["loss"])) < 5e-6, (i, a["loss"].item(), float(b["loss"]))
+        assert abs(float(a["perplexity"]) - float(b["perplexity"])) < 1e-4, i
+
+
 def test_single_rank_rccl_reducer_path_matches_plain_trainer(golden_dir):
     """The data-parallel path on ONE rank (RCCL communicator of size 1, hooks forced): gradients flow through the multi-tensor
     pack -> flat buckets -> HipAdamW-in-place route and must reproduce the plain trainer's loss trajectory exactly."""
