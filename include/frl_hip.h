@@ -64,6 +64,10 @@ int frl_conv1x1_fwd(const void* x, const float* w, const float* bias, void* y, i
                     int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
 int frl_conv1x1_bwd_data(const void* dy, const void* y, int act, const float* w, void* dx, int64_t P, int Cin, int Cout,
                          int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
+/* Backward-pass accumulation in the epilogue (autograd's sum of the gradients of a tensor with two consumers, fused into the
+ * kernel that produces one of them): dx = (dy .* act'(y)) W + add.  add [P][Cin] must not alias dx. */
+int frl_conv1x1_bwd_data_add(const void* dy, const void* y, int act, const float* w, void* dx, const void* add, int64_t P,
+                             int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
 /* Tuning hook (no reference counterpart): upper bound of the workgroups, i.e. float32 partial slabs, of a 1x1 weight-gradient launch;
  * returns the previous bound.  frl_conv1x1_bwd_weight_workspace_bytes follows it: size workspaces after changing it. */
 int frl_wgrad_set_max_workgroups(int n);
@@ -84,6 +88,12 @@ int frl_conv3x3_fwd(const void* x, const float* w, const float* bias, void* y, i
                     int act, int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
 int frl_conv3x3_bwd_data(const void* dy, const void* y, int act, const float* w, void* dx, int B, int H, int W, int Cin,
                          int Cout, int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
+/* frl_conv3x3_bwd_data with epilogue extras: dx = conv(...) + add (add may be null); with the pair sub_from / out2 (both or neither)
+ * also out2 = sub_from - dx.  EdgeAwareSmoothingConv2D's backward uses both: the residual's two gradient streams are summed here and
+ * d_smoothed - d_residual leaves in the same launch (spatial.py:331-339: residual = x - smoothed feeds the gate net and the blend). */
+int frl_conv3x3_bwd_data_fused(const void* dy, const void* y, int act, const float* w, void* dx, const void* add,
+                               const void* sub_from, void* out2, int B, int H, int W, int Cin, int Cout, int dtype, void* ws,
+                               size_t ws_bytes, frl_stream_t stream);
 size_t frl_conv3x3_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int frl_conv3x3_bwd_weight(const void* dy, const void* y, int act, const void* x, float* dw, float* dbias, int B, int H,
                            int W, int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, int flags, frl_stream_t stream);
@@ -126,6 +136,8 @@ int frl_encoder2_bwd(const void* x, const void* dz, const float* w1, const float
  * Sobel/4 depthwise gradients (frl/models/spatial.py:240-249,295-296): g [B][H][W][2C] = cat[dx, dy]. */
 int frl_sobel_fwd(const void* x, void* g, int B, int H, int W, int C, int dtype, frl_stream_t stream);
 int frl_sobel_bwd(const void* dg, void* dx, int B, int H, int W, int C, int dtype, frl_stream_t stream);
+/* dx = sobel^T(dg) + dx_add (dx_add [B][H][W][C] or null): x also feeds the filter bank, whose dx arrives through dx_add */
+int frl_sobel_bwd_add(const void* dg, void* dx, const void* dx_add, int B, int H, int W, int C, int dtype, frl_stream_t stream);
 /* directional bank + rank-R mixing (spatial.py:224-237,300-331): a_logit [P][8R] (k*R+r), b_logit [P][C*R] (c*R+r);
  * outputs smoothed, residual = x - smoothed, and the softmaxed maps a_soft / b_soft saved for the backward. */
 int frl_edge_smooth_stencil_fwd(const void* x, const void* a_logit, const void* b_logit, void* smoothed, void* residual,

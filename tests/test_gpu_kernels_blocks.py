@@ -525,3 +525,79 @@ def test_fused_decoder_mse(P, cz, use_mask):
     assert rel_err(zd.grad.float(), z.grad) <= 3e-2
     for got, ref in zip(params, (w1q, b1d, w2q, b2d)):
         assert rel_err(got.grad, ref.grad) <= 3e-2
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 8e-3)])
+def test_backward_epilogue_sums_match_separate_launches(dtype, tol):
+    """conv3x3 / conv1x1 bwd-data and the Sobel transpose with the accumulation of a second gradient stream (and, for the 3x3, the
+    second output sub_from - dx) in their epilogues == the plain launch followed by torch arithmetic.  Shapes cover the 16-byte store
+    route (64 channels) and the scalar route."""
+    from frl_hip import ops
+    from frl_hip.ops import ACT_NONE, ACT_RELU
+    g = torch.Generator().manual_seed(77)
+
+    def rnd(*shape):
+        return torch.randn(*shape, generator=g).to(dtype).to(DEV)
+
+    for (B, H, W, cin, cout) in [(2, 16, 32, 64, 64), (1, 9, 11, 12, 8), (1, 8, 8, 128, 64)]:
+        w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).to(DEV)
+        dy, y, add, sub = rnd(B, H, W, cout), rnd(B, H, W, cout), rnd(B, H, W, cin), rnd(B, H, W, cin)
+        plain = ops.conv3x3_bwd_data(dy, w, y, ACT_RELU).float()
+        dx = ops.conv3x3_bwd_data(dy, w, y, ACT_RELU, add=add)
+        scale = plain.abs().max().item() + add.float().abs().max().item()
+        assert (dx.float() - (plain + add.float())).abs().max().item() <= tol * scale
+        dx2, out2 = ops.conv3x3_bwd_data(dy, w, y, ACT_RELU, add=add, sub_from=sub)
+        assert torch.equal(dx2, dx)
+        assert (out2.float() - (sub.float() - dx.float())).abs().max().item() <= tol * scale
+        dx3, out3 = ops.conv3x3_bwd_data(dy, w, y, ACT_RELU, sub_from=sub)
+        assert (dx3.float() - plain).abs().max().item() <= tol * scale
+        assert (out3.float() - (sub.float() - dx3.float())).abs().max().item() <= tol * scale
+    for (P, cin, cout) in [(4096, 64, 32), (333, 12, 20), (1000, 64, 256), (130, 8, 4)]:
+        w = (torch.randn(cout, cin, generator=g) * 0.2).to(DEV)
+        dy, add = rnd(P, cout), rnd(P, cin)
+        plain = ops.conv1x1_bwd_data(dy, w, None, ACT_NONE).float()
+        dx = ops.conv1x1_bwd_data(dy, w, None, ACT_NONE, add=add)
+        assert (dx.float() - (plain + add.float())).abs().max().item() <= tol * (plain.abs().max().item() + 4.0)
+    for (B, H, W, C) in [(2, 16, 16, 64), (1, 7, 9, 8)]:
+        dg, add = rnd(B, H, W, 2 * C), rnd(B, H, W, C)
+        plain = ops.sobel_bwd(dg).float()
+        assert (ops.sobel_bwd(dg, add=add).float() - (plain + add.float())).abs().max().item() <= tol * (plain.abs().max().item() + 4.0)
+    with pytest.raises(ValueError):
+        ops.sobel_bwd(rnd(1, 4, 4, 16), add=rnd(1, 4, 4, 16))                 # add must have dx's shape, not dg's
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("B,H,W,C,hidden", [(2, 32, 32, 64, 64), (1, 9, 13, 16, 24)])
+def test_spatial_smoothing_block_as_one_autograd_node_matches_the_modular_chain(dtype, tol, B, H, W, C, hidden):
+    """EdgeAwareSmoothingConv2D: fuse=True (Fh.SpatialSmoothFn, gradient sums in kernel epilogues) against fuse=False (one autograd
+    node per kernel, sums by autograd).  The forward kernels are the same launches, so outputs are bit-equal; gradients agree to the
+    rounding of the intermediate sums."""
+    from frl_hip.models.blocks import EdgeAwareSmoothingConv2D
+    torch.manual_seed(5 + C)
+    m = EdgeAwareSmoothingConv2D(C, gate_hidden=hidden).to(DEV)
+    m.set_min_gate(0.1)
+    x0 = (torch.randn(B, H, W, C, generator=torch.Generator().manual_seed(9)) * 0.7).to(dtype).to(DEV)
+    dout = torch.randn(B, H, W, C, generator=torch.Generator().manual_seed(10)).to(dtype).to(DEV)
+    dgate = (torch.randn(B, H, W, C, generator=torch.Generator().manual_seed(11)) * 0.3).to(dtype).to(DEV)
+    res = {}
+    for fuse in (False, True):
+        m.fuse = fuse
+        m.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        out, gate = m(x, return_gate=True)
+        torch.autograd.backward([out, gate], [dout, dgate])
+        res[fuse] = (out.detach(), gate.detach(), x.grad.detach().float(), {n: p.grad.detach().clone() for n, p in m.named_parameters()})
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    gx_f, gx_m = res[True][2], res[False][2]
+    assert (gx_f - gx_m).abs().max().item() <= tol * gx_m.abs().max().item()
+    for n, gm in res[False][3].items():
+        gf = res[True][3][n]
+        assert (gf - gm).abs().max().item() <= tol * max(gm.abs().max().item(), 1e-6), n
+    # the gate output may carry no gradient at all (return_gate=False callers)
+    m.fuse = True
+    x = x0.clone().requires_grad_(True)
+    m(x).backward(dout)
+    m.fuse = False
+    x2 = x0.clone().requires_grad_(True)
+    m(x2).backward(dout)
+    assert (x.grad.float() - x2.grad.float()).abs().max().item() <= tol * x2.grad.float().abs().max().item()

@@ -158,11 +158,14 @@ __device__ __forceinline__ void c3_halo_commit(const C3Halo<T, CK, NTHR>& h, T* 
 #ifdef C3_STAMPS
 __device__ unsigned long long* c3_dbg;       // diagnostic build only (tools/diag/c3_stamps.hip)
 #endif
-template <typename T, int NF>
+template <typename T, int NF, bool EPI = false>
 __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, const T* __restrict__ Xmask, int mask_act,
                                                       const typename DT<T>::frag_t* __restrict__ Wpk,
                                                       const float* __restrict__ bias, T* __restrict__ Y, int B, int H, int W,
-                                                      int Cin, int Cout, int act) {
+                                                      int Cin, int Cout, int act, const T* __restrict__ Yadd,
+                                                      const T* __restrict__ Ysub, T* __restrict__ Y2) {
+  // Yadd (optional): Y = act(conv + bias) + Yadd.  Ysub/Y2 (optional pair): Y2 = Ysub - Y.  Both ride in the epilogue so that a
+  // backward pass can fold the gradient accumulation of a tensor with two consumers into the convolution that produces one of them.
   typedef typename DT<T>::frag_t frag_t;
   constexpr int FE = DT<T>::FE;
   constexpr int q = NF * FE, CK = 4 * q;
@@ -295,6 +298,31 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
 #pragma unroll
           for (int j = 0; j < 16; ++j) v[j] = sigmoid_t<T>(v[j]);
         }
+        if constexpr (EPI) {
+          // one channel vector at a time: add, store, and the second output from the value as it was rounded for the store
+          const int64_t yo = (yp - Y) + cb;
+#pragma unroll
+          for (int j = 0; j < 16; j += DT<T>::VEC) {
+            float o[DT<T>::VEC];
+#pragma unroll
+            for (int e = 0; e < DT<T>::VEC; ++e) o[e] = v[j + e];
+            if (Yadd != nullptr) {
+              float a[DT<T>::VEC];
+              Vec<T>::load(Yadd + yo + j, a);
+#pragma unroll
+              for (int e = 0; e < DT<T>::VEC; ++e) o[e] += a[e];
+            }
+            Vec<T>::store(Y + yo + j, o);
+            if (Y2 != nullptr) {
+              float a[DT<T>::VEC];
+              Vec<T>::load(Ysub + yo + j, a);
+#pragma unroll
+              for (int e = 0; e < DT<T>::VEC; ++e) a[e] -= to_f32(from_f32<T>(o[e]));
+              Vec<T>::store(Y2 + yo + j, a);
+            }
+          }
+          continue;
+        }
 #pragma unroll
         for (int j = 0; j < 16; j += DT<T>::VEC) Vec<T>::store(yp + cb + j, v + j);
         continue;
@@ -309,6 +337,18 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
           const int c = cb + r;
           const float bb = c < Cout ? bias_l[c] : 0.f;
           v[r] = act_fwd(acc[t][m][r] + bb, act);
+        }
+        if (EPI && (Yadd != nullptr || Y2 != nullptr)) {         // scalar route: these epilogues are rare off the fast path
+          const int64_t yo = yp - Y;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (cb + r >= Cout) continue;
+            if (Yadd != nullptr) v[r] += to_f32(Yadd[yo + cb + r]);
+            const T o = from_f32<T>(v[r]);
+            yp[cb + r] = o;
+            if (Y2 != nullptr) Y2[yo + cb + r] = from_f32<T>(to_f32(Ysub[yo + cb + r]) - to_f32(o));
+          }
+          continue;
         }
         if ((Cout & 3) == 0 && cb + 3 < Cout) {
           if constexpr (FE == 8) *reinterpret_cast<bf16x4*>(yp + cb) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
@@ -508,7 +548,7 @@ struct C3Epi {
 template <typename T, int NF>
 static int launch_c3(const void* x, const void* xm, int mask_act, const float* w, int64_t so, int64_t si, int tap_rev,
                      const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act, void* ws, size_t ws_bytes,
-                     hipStream_t st) {
+                     hipStream_t st, const void* yadd = nullptr, const void* ysub = nullptr, void* y2 = nullptr) {
   typedef typename DT<T>::frag_t frag_t;
   constexpr int CK = 4 * NF * DT<T>::FE;
   const int MBt = (Cout + 15) / 16;
@@ -524,25 +564,27 @@ static int launch_c3(const void* x, const void* xm, int mask_act, const float* w
   const size_t lds = (size_t)(C3F_TH + 2) * C3_WP * (CK + C3<T>::PADE) * sizeof(T) + (size_t)9 * 4 * NF * 64 * sizeof(frag_t) +
                      (size_t)((Cout + 15) / 16 * 16) * sizeof(float);
   if (lds > 160 * 1024) return frl_fail(-3, "conv3x3: LDS budget exceeded");
-  auto kern = conv3x3_kernel<T, NF>;
+  const bool epi = yadd != nullptr || y2 != nullptr;            // the epilogue extras are their own instantiation: the plain one keeps its registers
+  auto kern = epi ? conv3x3_kernel<T, NF, true> : conv3x3_kernel<T, NF, false>;
   FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int tiles = B * ((H + C3F_TH - 1) / C3F_TH) * ((W + C3_TW - 1) / C3_TW);
   const int grid = tiles < 256 ? tiles : 256;                  // LDS allows one workgroup per CU: persistent over the tiles
   FRL_LAUNCH_AS("conv3x3_kernel", kern, dim3(grid), dim3(512), lds, st, (const T*)x, (const T*)xm, mask_act, pk, bias, (T*)y, B,
-                     H, W, Cin, Cout, act);
+                     H, W, Cin, Cout, act, (const T*)yadd, (const T*)ysub, (T*)y2);
   return frl_check_launch("conv3x3");
 }
 
 static int c3_dispatch(const void* x, const void* xm, int mask_act, const float* w, int64_t so, int64_t si, int tap_rev,
                        const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act, int dtype, void* ws, size_t ws_bytes,
-                       hipStream_t st) {
+                       hipStream_t st, const void* yadd = nullptr, const void* ysub = nullptr, void* y2 = nullptr) {
   if (B <= 0 || H <= 0 || W <= 0) return frl_fail(-2, "conv3x3: empty input");
+  if ((ysub == nullptr) != (y2 == nullptr)) return frl_fail(-2, "conv3x3: sub_from and out2 come as a pair");
   if (dtype == FRL_F32) {
-    if (Cin <= 16) return launch_c3<float, 4>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st);
-    return launch_c3<float, 8>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st);
+    if (Cin <= 16) return launch_c3<float, 4>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st, yadd, ysub, y2);
+    return launch_c3<float, 8>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st, yadd, ysub, y2);
   } else if (dtype == FRL_BF16) {
-    if (Cin <= 32) return launch_c3<bf16, 1>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st);
-    return launch_c3<bf16, 2>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st);
+    if (Cin <= 32) return launch_c3<bf16, 1>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st, yadd, ysub, y2);
+    return launch_c3<bf16, 2>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st, yadd, ysub, y2);
   }
   return frl_fail(-2, "conv3x3: bad dtype");
 }
@@ -571,6 +613,15 @@ int frl_conv3x3_bwd_data(const void* dy, const void* y, int act, const float* w,
                          int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
   return c3_dispatch(dy, act != FRL_ACT_NONE ? y : nullptr, act, w, 9, (int64_t)Cin * 9, 1, nullptr, dx, B, H, W, Cout, Cin,
                      FRL_ACT_NONE, dtype, ws, ws_bytes, stream);
+}
+
+// The same with the epilogue extras: dx = conv(...) + add (add may be null); with sub_from/out2 (a pair, may be null) also
+// out2 = sub_from - dx.  None of the extras may alias dx.
+int frl_conv3x3_bwd_data_fused(const void* dy, const void* y, int act, const float* w, void* dx, const void* add, const void* sub_from,
+                               void* out2, int B, int H, int W, int Cin, int Cout, int dtype, void* ws, size_t ws_bytes,
+                               hipStream_t stream) {
+  return c3_dispatch(dy, act != FRL_ACT_NONE ? y : nullptr, act, w, 9, (int64_t)Cin * 9, 1, nullptr, dx, B, H, W, Cout, Cin,
+                     FRL_ACT_NONE, dtype, ws, ws_bytes, stream, add, sub_from, out2);
 }
 
 size_t frl_conv3x3_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout) {

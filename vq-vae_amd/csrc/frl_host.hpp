@@ -50,4 +50,4 @@ void frl_timing_end(hipStream_t st);
 // internal cross-file dispatchers
 int frl_pw_dispatch(const void* x, const void* xmask, int mask_act, const float* w, int64_t so, int64_t si,
                     const float* bias, void* y, int64_t P, int Cin, int Cout, int act, int dtype, void* ws, size_t ws_bytes,
-                    hipStream_t st);
+                    hipStream_t st, const void* yadd = nullptr);

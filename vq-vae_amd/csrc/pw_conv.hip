@@ -14,7 +14,8 @@
 template <typename T, int NF, int NT>
 __global__ __launch_bounds__(256) void pw_conv_kernel(
     const T* __restrict__ X, const T* __restrict__ Xmask, int mask_act, const typename DT<T>::frag_t* __restrict__ Wpk,
-    const float* __restrict__ bias, T* __restrict__ Y, int64_t P, int Cin, int Cout, int act) {
+    const float* __restrict__ bias, T* __restrict__ Y, int64_t P, int Cin, int Cout, int act, const T* __restrict__ Yadd) {
+  // Yadd (optional): Y = act(W x + bias) + Yadd -- lets a backward pass accumulate the gradient of a tensor with two consumers
   typedef typename DT<T>::frag_t frag_t;
   constexpr int FE = DT<T>::FE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -89,6 +90,15 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = sigmoid_t<T>(v[j]);
           }
+          if (Yadd != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 16; j += DT<T>::VEC) {
+              float a[DT<T>::VEC];
+              Vec<T>::load(Yadd + rows[t] * (int64_t)Cout + cb + j, a);
+#pragma unroll
+              for (int e = 0; e < DT<T>::VEC; ++e) v[j + e] += a[e];
+            }
+          }
 #pragma unroll
           for (int j = 0; j < 16; j += DT<T>::VEC) Vec<T>::store(yp + cb + j, v + j);
           continue;
@@ -103,6 +113,7 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(
             const int c = cb + r;
             const float b = c < Cout ? bias_l[c] : 0.f;
             v[r] = act_fwd(acc[t][m][r] + b, act);
+            if (Yadd != nullptr && c < Cout) v[r] += to_f32(Yadd[rows[t] * (int64_t)Cout + c]);
           }
           if (vec4_out && cb + 3 < Cout) {
             if constexpr (FE == 8) {
@@ -124,7 +135,8 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(
 
 template <typename T, int NF>
 static int launch_pw(const void* x, const void* xmask, int mask_act, const float* w, int64_t so, int64_t si,
-                     const float* bias, void* y, int64_t P, int Cin, int Cout, int act, void* ws, size_t ws_bytes, hipStream_t st) {
+                     const float* bias, void* y, int64_t P, int Cin, int Cout, int act, void* ws, size_t ws_bytes, hipStream_t st,
+                     const void* yadd) {
   typedef typename DT<T>::frag_t frag_t;
   constexpr int NT = 1;
   const int MB = (Cout + 15) / 16;
@@ -146,28 +158,29 @@ static int launch_pw(const void* x, const void* xmask, int mask_act, const float
   if (grid > 4096) grid = 4096;
   if (grid < 1) grid = 1;
   FRL_LAUNCH_AS("pw_conv_kernel", kern, dim3((unsigned)grid), dim3(256), lds, st, (const T*)x, (const T*)xmask, mask_act,
-             pk, bias, (T*)y, P, Cin, Cout, act);
+             pk, bias, (T*)y, P, Cin, Cout, act, (const T*)yadd);
   return frl_check_launch("pw_conv");
 }
 
 // Dispatch over padded input width.  f32: Cp in {16,32,64,128,256} -> NF = Cp/4; bf16: Cp in {32..256} -> NF = Cp/32.
 int frl_pw_dispatch(const void* x, const void* xmask, int mask_act, const float* w, int64_t so, int64_t si,
-                    const float* bias, void* y, int64_t P, int Cin, int Cout, int act, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
+                    const float* bias, void* y, int64_t P, int Cin, int Cout, int act, int dtype, void* ws, size_t ws_bytes, hipStream_t st,
+                    const void* yadd) {
   if (P <= 0) return 0;
   if (Cin < 1 || Cout < 1 || Cin > 512 || Cout > 1024) return frl_fail(-2, "pw_conv: unsupported channel count (Cin <= 512, Cout <= 1024)");
   if (dtype == FRL_F32) {
-    if (Cin <= 16) return launch_pw<float, 4>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
-    if (Cin <= 32) return launch_pw<float, 8>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
-    if (Cin <= 64) return launch_pw<float, 16>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
-    if (Cin <= 128) return launch_pw<float, 32>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
-    if (Cin <= 256) return launch_pw<float, 64>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
-    return launch_pw<float, 128>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);   // Cout <= 64 (LDS)
+    if (Cin <= 16) return launch_pw<float, 4>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st, yadd);
+    if (Cin <= 32) return launch_pw<float, 8>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st, yadd);
+    if (Cin <= 64) return launch_pw<float, 16>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st, yadd);
+    if (Cin <= 128) return launch_pw<float, 32>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st, yadd);
+    if (Cin <= 256) return launch_pw<float, 64>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st, yadd);
+    return launch_pw<float, 128>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st, yadd);   // Cout <= 64 (LDS)
   } else if (dtype == FRL_BF16) {
-    if (Cin <= 32) return launch_pw<bf16, 1>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
-    if (Cin <= 64) return launch_pw<bf16, 2>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
-    if (Cin <= 128) return launch_pw<bf16, 4>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
-    if (Cin <= 256) return launch_pw<bf16, 8>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);
-    return launch_pw<bf16, 16>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st);   // e.g. d(mix_head_B) at d = 128
+    if (Cin <= 32) return launch_pw<bf16, 1>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st, yadd);
+    if (Cin <= 64) return launch_pw<bf16, 2>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st, yadd);
+    if (Cin <= 128) return launch_pw<bf16, 4>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st, yadd);
+    if (Cin <= 256) return launch_pw<bf16, 8>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st, yadd);
+    return launch_pw<bf16, 16>(x, xmask, mask_act, w, so, si, bias, y, P, Cin, Cout, act, ws, ws_bytes, st, yadd);   // e.g. d(mix_head_B) at d = 128
   }
   return frl_fail(-2, "pw_conv: bad dtype");
 }
@@ -190,6 +203,13 @@ int frl_conv1x1_bwd_data(const void* dy, const void* y, int act, const float* w,
                          int Cout, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
   return frl_pw_dispatch(dy, act != FRL_ACT_NONE ? y : nullptr, act, w, 1, Cin, nullptr, dx, P, Cout, Cin,
                          FRL_ACT_NONE, dtype, ws, ws_bytes, stream);
+}
+
+// dx = (dy .* act'(y)) W + add: the accumulation of a second gradient stream into dx rides in the epilogue (add must not alias dx)
+int frl_conv1x1_bwd_data_add(const void* dy, const void* y, int act, const float* w, void* dx, const void* add, int64_t P, int Cin,
+                             int Cout, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+  return frl_pw_dispatch(dy, act != FRL_ACT_NONE ? y : nullptr, act, w, 1, Cin, nullptr, dx, P, Cout, Cin,
+                         FRL_ACT_NONE, dtype, ws, ws_bytes, stream, add);
 }
 
 }  // extern "C"

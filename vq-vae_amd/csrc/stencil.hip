@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void sobel_fwd_kernel(const T* __restrict__ X,
 }
 
 template <typename T, int V>
-__global__ __launch_bounds__(256) void sobel_bwd_kernel(const T* __restrict__ DG, T* __restrict__ DX, int B, int H, int W, int C) {
+__global__ __launch_bounds__(256) void sobel_bwd_kernel(const T* __restrict__ DG, T* __restrict__ DX, const T* __restrict__ DXADD, int B, int H, int W,
+                                                        int C) {
   const int vpr = C / V;
   const int64_t total = (int64_t)B * H * W * vpr;
   for (int64_t i = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -67,8 +68,12 @@ __global__ __launch_bounds__(256) void sobel_bwd_kernel(const T* __restrict__ DG
     const int64_t p = i / vpr;
     const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
     float o[V];
+    if (DXADD != nullptr) {                                      // gradient of x through its other consumer, accumulated here
+      Vec<T>::load(DXADD + p * C + c0, o);
+    } else {
 #pragma unroll
-    for (int e = 0; e < V; ++e) o[e] = 0.f;
+      for (int e = 0; e < V; ++e) o[e] = 0.f;
+    }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -626,13 +631,24 @@ int frl_sobel_fwd(const void* x, void* g, int B, int H, int W, int C, int dtype,
   return frl_check_launch("sobel_fwd");
 }
 
-int frl_sobel_bwd(const void* dg, void* dx, int B, int H, int W, int C, int dtype, hipStream_t stream) {
+static int sobel_bwd_launch(const void* dg, void* dx, const void* dx_add, int B, int H, int W, int C, int dtype, hipStream_t stream) {
   if (dtype == FRL_F32 && C % 4 == 0)
-    FRL_LAUNCH((sobel_bwd_kernel<float, 4>), dim3(st_grid((int64_t)B * H * W * (C / 4))), dim3(256), 0, stream, (const float*)dg, (float*)dx, B, H, W, C);
+    FRL_LAUNCH((sobel_bwd_kernel<float, 4>), dim3(st_grid((int64_t)B * H * W * (C / 4))), dim3(256), 0, stream, (const float*)dg, (float*)dx,
+               (const float*)dx_add, B, H, W, C);
   else if (dtype == FRL_BF16 && C % 8 == 0)
-    FRL_LAUNCH((sobel_bwd_kernel<bf16, 8>), dim3(st_grid((int64_t)B * H * W * (C / 8))), dim3(256), 0, stream, (const bf16*)dg, (bf16*)dx, B, H, W, C);
+    FRL_LAUNCH((sobel_bwd_kernel<bf16, 8>), dim3(st_grid((int64_t)B * H * W * (C / 8))), dim3(256), 0, stream, (const bf16*)dg, (bf16*)dx,
+               (const bf16*)dx_add, B, H, W, C);
   else return frl_fail(-2, "sobel: C must be a multiple of 8 (bf16) / 4 (f32)");
   return frl_check_launch("sobel_bwd");
+}
+
+int frl_sobel_bwd(const void* dg, void* dx, int B, int H, int W, int C, int dtype, hipStream_t stream) {
+  return sobel_bwd_launch(dg, dx, nullptr, B, H, W, C, dtype, stream);
+}
+
+// dx = sobel^T(dg) + dx_add  (dx_add [B][H][W][C], may be null)
+int frl_sobel_bwd_add(const void* dg, void* dx, const void* dx_add, int B, int H, int W, int C, int dtype, hipStream_t stream) {
+  return sobel_bwd_launch(dg, dx, dx_add, B, H, W, C, dtype, stream);
 }
 
 // x [P][C]; a_logit [P][8*R] (channel k*R+r); b_logit [P][C*R] (channel c*R+r).

@@ -39,6 +39,7 @@ SIGNATURES = {
     "frl_conv_workspace_bytes": (S, [I, I, I]),
     "frl_conv1x1_fwd": (c_int, [P, P, P, P, L, I, I, I, I, P, S, P]),
     "frl_conv1x1_bwd_data": (c_int, [P, P, I, P, P, L, I, I, I, P, S, P]),
+    "frl_conv1x1_bwd_data_add": (c_int, [P, P, I, P, P, P, L, I, I, I, P, S, P]),
     "frl_wgrad_set_max_workgroups": (c_int, [I]),
     "frl_conv3x3_wgrad_force_generic": (c_int, [I]),
     "frl_conv1x1_bwd_weight_workspace_bytes": (S, [L, I, I]),
@@ -85,10 +86,12 @@ SIGNATURES = {
     "frl_normalize_chunk_tiles": (c_int, [P, I, I, I, I, I, P, I, I, P, P, I, P, P]),
     "frl_conv3x3_fwd": (c_int, [P, P, P, P, I, I, I, I, I, I, I, P, S, P]),
     "frl_conv3x3_bwd_data": (c_int, [P, P, I, P, P, I, I, I, I, I, I, P, S, P]),
+    "frl_conv3x3_bwd_data_fused": (c_int, [P, P, I, P, P, P, P, P, I, I, I, I, I, I, P, S, P]),
     "frl_conv3x3_bwd_weight_workspace_bytes": (S, [I, I, I, I, I]),
     "frl_conv3x3_bwd_weight": (c_int, [P, P, I, P, P, P, I, I, I, I, I, I, P, S, I, P]),
     "frl_sobel_fwd": (c_int, [P, P, I, I, I, I, I, P]),
     "frl_sobel_bwd": (c_int, [P, P, I, I, I, I, I, P]),
+    "frl_sobel_bwd_add": (c_int, [P, P, P, I, I, I, I, I, P]),
     "frl_edge_smooth_stencil_fwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "frl_edge_smooth_stencil_bwd": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "frl_tcn_block_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, F, I, P, S, P]),

@@ -180,6 +180,55 @@ class GateBlendFn(Function):
         return dout, dres, dgraw, None
 
 
+class SpatialSmoothFn(Function):
+    """EdgeAwareSmoothingConv2D.forward (spatial.py:278-339) as ONE autograd node over the same kernels as the modular chain
+    SobelFn -> conv3x3 -> two 1x1 heads -> EdgeSmoothFn -> conv3x3 x2 -> GateBlendFn.  The point is the backward: three tensors of the
+    block have two consumers each (x: Sobel + filter bank; feat: the two heads; residual: gate net + blend) and autograd sums their
+    gradients with separate elementwise launches; here each sum rides in the epilogue of the kernel that produces its second term,
+    and d_smoothed - d_residual leaves the gate net's bwd-data launch as a second output."""
+
+    @staticmethod
+    def forward(ctx, x, w_mb, b_mb, w_a, b_a, w_b, b_b, w_g0, b_g0, w_g2, b_g2, rank, dil, min_gate):
+        g = ops.sobel_fwd(x)
+        feat = ops.conv3x3_fwd(g, w_mb, b_mb, ACT_RELU)
+        a_logit = ops.conv1x1_fwd(feat, w_a, b_a, ACT_NONE)
+        b_logit = ops.conv1x1_fwd(feat, w_b, b_b, ACT_NONE)
+        sm, res, a_soft, b_soft = ops.edge_smooth_fwd(x, a_logit, b_logit, rank, dil)
+        g1 = ops.conv3x3_fwd(res, w_g0, b_g0, ACT_RELU)
+        gate_raw = ops.conv3x3_fwd(g1, w_g2, b_g2, ACT_SIGMOID)
+        out, gate = ops.gate_blend_fwd(sm, res, gate_raw, min_gate)
+        ctx.cfg = (rank, dil, min_gate)
+        ctx.has_bias = tuple(b is not None for b in (b_mb, b_a, b_b, b_g0, b_g2))
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, g, feat, a_soft, b_soft, res, g1, gate_raw, w_mb, w_a, w_b, w_g0, w_g2)
+        return out, gate
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout, dgate):
+        x, g, feat, a_soft, b_soft, res, g1, gate_raw, w_mb, w_a, w_b, w_g0, w_g2 = ctx.saved_tensors
+        rank, dil, min_gate = ctx.cfg
+        dout = torch.zeros_like(res) if dout is None else _c(dout)
+        dres, dgraw = ops.gate_blend_bwd(dout, _c(dgate), res, gate_raw, min_gate)
+        dg1 = ops.conv3x3_bwd_data(dgraw, w_g2, gate_raw, ACT_SIGMOID)
+        dw_g2, db_g2 = ops.conv3x3_bwd_weight(dgraw, g1, gate_raw, ACT_SIGMOID)
+        # residual: blend term + gate-net term in one store; d(smoothed) - d(residual) (residual = x - smoothed) as the second output
+        dres_tot, d_tot = ops.conv3x3_bwd_data(dg1, w_g0, g1, ACT_RELU, add=dres, sub_from=dout)
+        dw_g0, db_g0 = ops.conv3x3_bwd_weight(dg1, res, g1, ACT_RELU)
+        dx, da, db = ops.edge_smooth_bwd(d_tot, x, a_soft, b_soft, rank, dil, dx_add=dres_tot)
+        dfeat = ops.conv1x1_bwd_data(db, w_b, None, ACT_NONE, add=ops.conv1x1_bwd_data(da, w_a, None, ACT_NONE))
+        dw_a, db_a = ops.conv1x1_bwd_weight(da, feat, None, ACT_NONE, want_bias=ctx.has_bias[1])
+        dw_b, db_b = ops.conv1x1_bwd_weight(db, feat, None, ACT_NONE, want_bias=ctx.has_bias[2])
+        dw_mb, db_mb = ops.conv3x3_bwd_weight(dfeat, g, feat, ACT_RELU)
+        if ctx.needs_input_grad[0]:
+            dx = ops.sobel_bwd(ops.conv3x3_bwd_data(dfeat, w_mb, feat, ACT_RELU), add=dx)
+        else:
+            dx = None
+        hb = ctx.has_bias
+        return (dx, dw_mb, db_mb if hb[0] else None, dw_a.reshape(w_a.shape), db_a if hb[1] else None, dw_b.reshape(w_b.shape),
+                db_b if hb[2] else None, dw_g0, db_g0 if hb[3] else None, dw_g2, db_g2 if hb[4] else None, None, None, None)
+
+
 class TcnBlockFn(Function):
     """Fused GatedResidualBlock on x [B,T,HW..,Cin]."""
 

@@ -204,7 +204,15 @@ class EdgeAwareSmoothingConv2D(nn.Module):
     def set_min_gate(self, value: float) -> None:
         self.min_gate = float(value)
 
+    fuse = True     # one autograd node for the block (Fh.SpatialSmoothFn: gradient sums in kernel epilogues); False = modular chain
+
     def forward(self, x: torch.Tensor, return_gate: bool = False):
+        if self.fuse:
+            mb, g0, g2 = self.mix_backbone[0], self.gate_net[0], self.gate_net[2]
+            out, gate = Fh.SpatialSmoothFn.apply(x, mb.weight, mb.bias, self.mix_head_A.weight, self.mix_head_A.bias,
+                                                 self.mix_head_B.weight, self.mix_head_B.bias, g0.weight, g0.bias, g2.weight, g2.bias,
+                                                 self.rank, self.coarse_dilation, self.min_gate)
+            return (out, gate) if return_gate else out
         g = Fh.SobelFn.apply(x)                                   # [B,H,W,2C] = cat[dx, dy]
         feat = self.mix_backbone[0](g, ACT_RELU)
         a_logit = self.mix_head_A(feat)

@@ -146,6 +146,13 @@ def _chk_rows(t: torch.Tensor, c: int, name: str):
         raise ValueError(f"{name}: expected contiguous [..., {c}] rows, got {tuple(t.shape)} stride {t.stride()}")
 
 
+def _chk_like(t: torch.Tensor, ref: torch.Tensor, name: str):
+    """An epilogue operand read at the addresses the kernel writes: same shape, dtype and device, contiguous, not the output itself."""
+    if t.shape != ref.shape or t.dtype != ref.dtype or t.device != ref.device or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous {tuple(ref.shape)} {ref.dtype} tensor on {ref.device}, got "
+                         f"{tuple(t.shape)} {t.dtype} stride {t.stride()}")
+
+
 def _f32(t: Optional[torch.Tensor], name: str):
     if t is None:
         return None
@@ -182,7 +189,9 @@ def conv1x1_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], 
 
 
 @_timed("conv1x1_bwd_data")
-def conv1x1_bwd_data(dy: torch.Tensor, w: torch.Tensor, y: Optional[torch.Tensor] = None, act: int = ACT_NONE) -> torch.Tensor:
+def conv1x1_bwd_data(dy: torch.Tensor, w: torch.Tensor, y: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+                     add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx = (dy .* act'(y)) W (+ add: a second gradient stream of x, accumulated in the kernel's epilogue)."""
     cout, cin = w.shape[0], w.shape[1]
     _chk_rows(dy, cout, "conv1x1_bwd_data.dy")
     w = _f32(w.reshape(cout, cin), "w")
@@ -190,6 +199,11 @@ def conv1x1_bwd_data(dy: torch.Tensor, w: torch.Tensor, y: Optional[torch.Tensor
     p = dy.numel() // cout
     lib = _lib.load()
     ws = workspace(lib.frl_conv_workspace_bytes(cin, cout, 1), dy.device)
+    if add is not None:
+        _chk_like(add, dx, "conv1x1_bwd_data.add")
+        check(lib.frl_conv1x1_bwd_data_add(_p(dy), _p(y), act, _p(w), _p(dx), _p(add), p, cin, cout, _dt(dy), _p(ws), ws.numel(),
+                                           _stream()), "frl_conv1x1_bwd_data_add")
+        return dx
     check(lib.frl_conv1x1_bwd_data(_p(dy), _p(y), act, _p(w), _p(dx), p, cin, cout, _dt(dy), _p(ws), ws.numel(), _stream()),
           "frl_conv1x1_bwd_data")
     return dx
@@ -575,12 +589,23 @@ def conv3x3_fwd(x, w, bias, act: int = ACT_NONE):
 
 
 @_timed("conv3x3_bwd_data")
-def conv3x3_bwd_data(dy, w, y=None, act: int = ACT_NONE):
+def conv3x3_bwd_data(dy, w, y=None, act: int = ACT_NONE, add=None, sub_from=None):
+    """dx = conv3x3^T(dy .* act'(y)) (+ add).  With sub_from the call returns (dx, sub_from - dx): both extras ride in the epilogue."""
     b, h, wd, cout = dy.shape
     cin = w.shape[1]
     dx = torch.empty(b, h, wd, cin, dtype=dy.dtype, device=dy.device)
     lib = _lib.load()
     ws = workspace(lib.frl_conv_workspace_bytes(cin, cout, 9), dy.device)
+    if add is not None or sub_from is not None:
+        out2 = None
+        if add is not None:
+            _chk_like(add, dx, "conv3x3_bwd_data.add")
+        if sub_from is not None:
+            _chk_like(sub_from, dx, "conv3x3_bwd_data.sub_from")
+            out2 = torch.empty_like(dx)
+        check(lib.frl_conv3x3_bwd_data_fused(_p(dy), _p(y), act, _p(_f32(w, "w")), _p(dx), _p(add), _p(sub_from), _p(out2), b, h, wd,
+                                             cin, cout, _dt(dy), _p(ws), ws.numel(), _stream()), "frl_conv3x3_bwd_data_fused")
+        return dx if sub_from is None else (dx, out2)
     check(lib.frl_conv3x3_bwd_data(_p(dy), _p(y), act, _p(_f32(w, "w")), _p(dx), b, h, wd, cin, cout, _dt(dy), _p(ws),
                                    ws.numel(), _stream()), "frl_conv3x3_bwd_data")
     return dx
@@ -611,9 +636,13 @@ def sobel_fwd(x):
 
 
 @_timed("sobel_bwd")
-def sobel_bwd(dg):
+def sobel_bwd(dg, add=None):
     b, h, w, c2 = dg.shape
     dx = torch.empty(b, h, w, c2 // 2, dtype=dg.dtype, device=dg.device)
+    if add is not None:
+        _chk_like(add, dx, "sobel_bwd.add")
+        check(_lib.load().frl_sobel_bwd_add(_p(dg), _p(dx), _p(add), b, h, w, c2 // 2, _dt(dg), _stream()), "frl_sobel_bwd_add")
+        return dx
     check(_lib.load().frl_sobel_bwd(_p(dg), _p(dx), b, h, w, c2 // 2, _dt(dg), _stream()), "frl_sobel_bwd")
     return dx
 
