@@ -1287,6 +1287,9 @@ static int launch_vq_prepare(const float* E, int64_t N, int K, int d, char* prep
   return frl_check_launch("vq_prepare");
 }
 
+#ifndef VQ_RES_NT
+#define VQ_RES_NT 4        // 16-row tiles per wave and batch of the resident kernel
+#endif
 template <typename T, int NF>
 static int launch_vq(const void* z, const float* E, char* prep, int64_t N, int K, int d, int32_t* idx, void* zq, float* stats,
                      int32_t* counts, char* ws, hipStream_t st) {
@@ -1308,7 +1311,7 @@ static int launch_vq(const void* z, const float* E, char* prep, int64_t N, int K
   if (resident) {
     // image | norms | histogram | per-row minima | parked rows | candidates | misc; the statistics fold of the last workgroup reuses the front
     const int nwr = (nw == 8 && NF <= (sizeof(T) == 2 ? 2 : 4)) ? 8 : 4;  // 8 waves x 4 tiles only where the tiles fit the 128-register budget
-    const int batch = nwr * 4 * 16;
+    const int batch = nwr * VQ_RES_NT * 16;
     const int64_t nb = (N + batch - 1) / batch;
     const int grid_r = (int)(nb < L.grid ? nb : L.grid);
     size_t lds = (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc * 4 + (size_t)((K + 1) & ~1) * 4 + (size_t)VQ_FAST_ROWS * 12 +
@@ -1318,7 +1321,7 @@ static int launch_vq(const void* z, const float* E, char* prep, int64_t N, int K
     if (lds > 160 * 1024) return frl_fail(-3, "vq_assign: LDS budget exceeded");
 #define VQ_GO(NW_)                                                                                                                 \
   do {                                                                                                                             \
-    auto kern = vq_assign_resident_kernel<T, NF, 4, NW_>;                                                                          \
+    auto kern = vq_assign_resident_kernel<T, NF, VQ_RES_NT, NW_>;                                                                          \
     if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
     FRL_LAUNCH_AS("vq_assign_kernel", kern, dim3(grid_r), dim3(64 * NW_), lds, st, (const T*)z, E, en, N, K, d, Kc, idx, (T*)zq,   \
                   (float*)(ws + L.partial), pk, (VqCtl*)(prep + P.ctl), counts, stats);                                            \
