@@ -72,3 +72,34 @@ def test_extract_at_locations_matches_reference(golden_dir):
     neg = coords.clone()
     neg[0] = torch.tensor([-1, -2], device=DEV)                                   # torch indexing semantics for negative indices
     assert torch.equal(extract_at_locations(feat, neg)[0], feat[:, -1, -2])
+
+
+def test_out_of_range_indices_are_flagged_not_dereferenced(monkeypatch):
+    """The reference's advanced indexing raises IndexError on an out-of-range coordinate / pair row; the kernels take raw pointers, so
+    the wrappers clamp such indices (no out-of-bounds read), raise a sticky device flag (`ops.index_errors`, no sync on the hot path)
+    and, with FRL_HIP_CHECK_INDICES=1, raise IndexError at once.  Negative indices wrap as in torch."""
+    from frl_hip import ops
+    from frl_hip.losses import contrastive_loss
+    from frl_hip.utils import extract_at_locations
+    ops.index_errors()
+    feat = torch.randn(4, 6, 5, device=DEV)
+    ok = torch.tensor([[0, 0], [5, 4], [-6, -5]], device=DEV)
+    assert torch.equal(extract_at_locations(feat, ok), torch.stack([feat[:, 0, 0], feat[:, 5, 4], feat[:, 0, 0]]))
+    assert not ops.index_errors()
+    bad = torch.tensor([[0, 0], [6, 0], [0, 1 << 40]], device=DEV)
+    out = extract_at_locations(feat, bad)                                          # clamped: finite values of the raster, no fault
+    assert torch.isfinite(out).all() and ops.index_errors() and not ops.index_errors()
+    emb = torch.randn(10, 8, device=DEV, requires_grad=True)
+    pos = torch.tensor([[0, 1], [2, -1]], device=DEV)                              # -1 = row 9
+    neg = torch.tensor([[0, 3], [2, 4]], device=DEV)
+    l_ref = contrastive_loss(emb, torch.tensor([[0, 1], [2, 9]], device=DEV), neg)
+    assert contrastive_loss(emb, pos, neg).item() == l_ref.item() and not ops.index_errors()
+    l_bad = contrastive_loss(emb, torch.tensor([[0, 1], [2, 10]], device=DEV), neg)
+    l_bad.backward()
+    assert torch.isfinite(emb.grad).all() and ops.index_errors()
+    monkeypatch.setenv("FRL_HIP_CHECK_INDICES", "1")
+    with pytest.raises(IndexError):
+        contrastive_loss(emb, torch.tensor([[0, 1], [2, 10]], device=DEV), neg)
+    with pytest.raises(IndexError):
+        extract_at_locations(feat, bad)
+    ops.index_errors()

@@ -337,6 +337,76 @@ def test_graph_captured_step_reproduces_the_eager_trajectory(golden_dir):
     assert int(m0.codebook_manager.revived.item()) == int(m1.codebook_manager.revived.item())
 
 
+def test_graphed_step_with_codebook_manager_over_several_revivals(golden_dir):
+    """Graph replays run no Python, so the CodebookManager's handles on the encoder rows / guard flag of "the current batch" must be
+    those of the graph that just ran: 8 steps over a ring of 3 input buffers with reset_every = 3 (the ring size does not divide it)
+    give two revivals, the second one after the manager has forgotten its rows once; a 9th..12th step on fresh tensors overflows
+    MAX_GRAPHS = 2 into the trainer's staging graph, which must leave the caller's tensors untouched.  A codebook far from the data
+    guarantees dead codes.  Parameters, usage window and revival count equal the eager trainer's bit for bit, and the warm-up steps of
+    the first capture leave nothing in the usage window."""
+    from frl_hip.training.codebook_manager import CodebookManager
+    from frl_hip.training.trainer import VQVAETrainer
+    fx = _load(golden_dir, "vqvae_tiny_seed0")
+    ring = [t.contiguous() for t in torch.from_numpy(fx["tiles"]).float().to(DEV)][:3]
+    extra = [(ring[i % 3] * (1.0 + 0.01 * i)).contiguous() for i in range(4)]
+    keep = [t.clone() for t in ring + extra]
+
+    def run(graphed):
+        m = _vqvae_from_fixture(fx)
+        with torch.no_grad():
+            m.quant.codebook[8:] += 50.0                                          # half of the codes can never win: dead
+        mgr = CodebookManager(num_codes=16, code_dim=8, reset_every=3, min_count=1)
+        m.attach_codebook_manager(mgr)
+        tr = VQVAETrainer(m, lr=1e-3, total_steps=16)
+        tr.MAX_GRAPHS = 2
+        windows = []
+        for i in range(12):
+            t = ring[i % 3] if i < 8 else extra[i - 8]
+            tr.step_graphed(t) if graphed else tr.step(t)
+            windows.append(mgr.window.clone())
+        torch.cuda.synchronize()
+        return m, tr, mgr, windows
+
+    m0, tr0, g0, w0 = run(False)
+    m1, tr1, g1, w1 = run(True)
+    assert tr1.graph_supported() and set(tr1._graphs) >= {"staging"} and len(tr1._graphs) == 3
+    assert int(w1[0].sum()) == 8 * 8                                               # one batch, not 1 + 2 warm-up batches
+    for a, b in zip(w0, w1):
+        assert torch.equal(a, b)
+    assert int(g0.revived.item()) == int(g1.revived.item()) >= 8 and g1.steps == 12
+    for (n, p), (_, q) in zip(m0.named_parameters(), m1.named_parameters()):
+        assert torch.equal(p, q), n
+    for t, k in zip(ring + extra, keep):
+        assert torch.equal(t, k)
+
+
+def test_graphed_step_sees_state_edited_behind_the_trainer(golden_dir):
+    """load_state_dict / manual edits between replays: the packed weight images and the codebook image are rebuilt before the next
+    replay, exactly as the eager step does (one step on stale images would apply gradients of the old weights to the new ones)."""
+    from frl_hip.training.trainer import VQVAETrainer
+    fx = _load(golden_dir, "vqvae_tiny_seed0")
+    tiles = [t.contiguous() for t in torch.from_numpy(fx["tiles"]).float().to(DEV)]
+
+    def run(graphed):
+        m = _vqvae_from_fixture(fx)
+        tr = VQVAETrainer(m, lr=1e-3, total_steps=8)
+        f = tr.step_graphed if graphed else tr.step
+        f(tiles[0]); f(tiles[0])
+        with torch.no_grad():
+            m.encoder.layers[0].weight.mul_(0.5)
+            m.quant.codebook.mul_(-1.0)
+        out = f(tiles[0])
+        loss = float(out["loss"].detach())
+        torch.cuda.synchronize()
+        return m, loss
+
+    m0, l0 = run(False)
+    m1, l1 = run(True)
+    assert l0 == l1
+    for (n, p), (_, q) in zip(m0.named_parameters(), m1.named_parameters()):
+        assert torch.equal(p, q), n
+
+
 def test_weight_image_cache_changes_nothing_but_the_launch_count():
     """VQVAETrainer(pack_cache=True): the packed MFMA fragment images of all conv weights are kept in the trainer's arena and rewritten
     by one launch behind the optimizer.  The generic repack kernel must reproduce the per-call pack kernels bit for bit: three steps

@@ -52,8 +52,9 @@ def contrastive_loss(embeddings: torch.Tensor, pos_pairs: torch.Tensor, neg_pair
         return torch.tensor(0.0, device=dev, dtype=embeddings.dtype)
     emb = embeddings if embeddings.dtype == torch.float32 else embeddings.float()
     emb = emb.contiguous()
-    pos_pairs = pos_pairs.to(dev, torch.int64).reshape(-1, 2)
-    neg_pairs = neg_pairs.to(dev, torch.int64).reshape(-1, 2)
+    # (the reference's emb[pairs[:, k]] raises on an out-of-range row; here such rows are wrapped / clamped and flagged: ops.index_errors)
+    pos_pairs = ops.sanitize_indices(pos_pairs.to(dev, torch.int64).reshape(-1, 2), emb.shape[0], "contrastive_loss: pos_pairs")
+    neg_pairs = ops.sanitize_indices(neg_pairs.to(dev, torch.int64).reshape(-1, 2), emb.shape[0], "contrastive_loss: neg_pairs")
     pw = torch.ones(pos_pairs.shape[0], device=dev) if pos_weights is None else pos_weights.to(dev, torch.float32)
     nw = torch.ones(neg_pairs.shape[0], device=dev) if neg_weights is None else neg_weights.to(dev, torch.float32)
     # negatives count only for anchors that have a positive (contrastive.py:160-170)

@@ -48,6 +48,39 @@ def kernel_timing_report():
     return out
 
 
+# ----------------------------------------------------------------------------------------------
+# Index validation of the sparse ops (gathers, pair lists).  The reference's advanced indexing raises on an out-of-range index; the
+# kernels take device pointers and would read out of bounds.  The Python wrappers therefore wrap negative indices, clamp the rest into
+# range and OR "something was out of range" into a device flag without a host synchronisation; `index_errors()` reads it, and with
+# FRL_HIP_CHECK_INDICES=1 the wrappers raise IndexError on the spot (one sync per call: debugging).
+# ----------------------------------------------------------------------------------------------
+_INDEX_FLAG = {}
+
+
+def sanitize_indices(idx: torch.Tensor, n: int, what: str) -> torch.Tensor:
+    """idx int64 (any shape) addressing n rows -> indices in [0, n): negatives wrapped as torch indexing does, out-of-range clamped and flagged."""
+    import os
+    bad = ((idx < -n) | (idx >= n)).any()
+    flag = _INDEX_FLAG.get(idx.device)
+    if flag is None:
+        flag = _INDEX_FLAG[idx.device] = torch.zeros(1, dtype=torch.int32, device=idx.device)
+    flag |= bad.to(torch.int32)
+    if os.environ.get("FRL_HIP_CHECK_INDICES", "0") == "1" and bool(bad.item()):
+        raise IndexError(f"{what}: index out of range for {n} rows")
+    return torch.where(idx < 0, idx + n, idx).clamp_(0, max(n - 1, 0))
+
+
+def index_errors(device=None, reset: bool = True) -> bool:
+    """True when any sparse op since the last call saw an out-of-range index on `device` (all devices when None); synchronises."""
+    hit = False
+    for dev, flag in _INDEX_FLAG.items():
+        if device is None or torch.device(device) == dev:
+            hit |= bool(flag.item())
+            if reset:
+                flag.zero_()
+    return hit
+
+
 class PackCache:
     """Weight-image cache of a trainer (include/frl_hip.h: frl_pack_cache_*): the packed MFMA fragment images of the model's weights live
     in an arena owned by this object; `with cache:` makes the conv-like calls use them, `refresh()` rewrites all of them in one launch."""

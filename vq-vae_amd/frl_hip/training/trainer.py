@@ -113,7 +113,7 @@ class VQVAETrainer:
             return self.step(tile, mask)
         # A graph reads its input at a fixed address.  Inputs that come from a small ring of device buffers (TilePrefetcher slots,
         # the benchmark's tile pool) get one graph per buffer -- all of them share one memory pool, they never run concurrently --
-        # so that no copy into a staging tensor is needed; beyond MAX_GRAPHS distinct buffers the input is copied into the first one.
+        # so that no copy into a staging tensor is needed; beyond MAX_GRAPHS distinct buffers the input is copied into a staging tile of the trainer's own.
         key = self._graph_key(tile, mask)
         graphs = self.__dict__.setdefault("_graphs", {})
         if graphs and next(iter(graphs.values()))["key"] != key:
@@ -122,13 +122,25 @@ class VQVAETrainer:
         slot = (tile.data_ptr(), None if mask is None else mask.data_ptr())
         g = graphs.get(slot)
         if g is None:
-            if len(graphs) < self.MAX_GRAPHS:
+            if sum(1 for k in graphs if k != "staging") < self.MAX_GRAPHS:
                 g = graphs[slot] = self._capture(tile, mask, key)
             else:
-                g = next(iter(graphs.values()))
+                # more distinct input addresses than graphs (a loader that yields a fresh tensor per step, a ring of more than MAX_GRAPHS
+                # slots): ONE further graph on buffers this trainer owns; the caller's tensors are only ever read
+                g = graphs.get("staging")
+                if g is None:
+                    g = graphs["staging"] = self._capture(tile.clone(), None if mask is None else mask.clone(), key)
+        # State edited behind the trainer's back since the last step (load_state_dict on resume, manual edits) -- the eager path checks
+        # parameter versions in step() and the quantizer re-keys its image in forward(); a replay runs no Python, so check here.
+        self._images_current()
+        if hasattr(self.model, "_quantizers"):
+            for qz in self.model._quantizers():
+                if qz._prepared is not None:
+                    qz.prepared(qz._prepared[0][2], 1 << 20)       # rebuilt (eagerly, into the same buffer) only when the key moved
         lr_now = cosine_lr(self.step_idx, self.total_steps, self.lr, self.min_lr)
-        g["lr_host"].fill_(lr_now)
-        self.opt.lr_dev.copy_(g["lr_host"], non_blocking=True)     # pinned word -> device word, on the stream of the replay
+        # the scalar travels as a kernel argument of the fill: no host word that a later step could overwrite before the copy engine
+        # has read it (the un-synchronised loop of bench.py queues many steps ahead of the device)
+        self.opt.lr_dev.fill_(lr_now)
         if g["tile"].data_ptr() != tile.data_ptr():
             g["tile"].copy_(tile, non_blocking=True)
         if mask is not None and g["mask"].data_ptr() != mask.data_ptr():
@@ -136,6 +148,10 @@ class VQVAETrainer:
         g["graph"].replay()
         mgr = getattr(self.model, "codebook_manager", None)
         if mgr is not None and hasattr(mgr, "after_step"):         # host-scheduled (every reset_every steps): stays outside the graph
+            # the rows / guard flag a revival would draw from are static outputs of THE GRAPH THAT JUST RAN: hand them to the manager
+            # before every after_step (it forgets them after a revival, and another graph's replay leaves its own buffers current)
+            if g.get("mgr_z") is not None:
+                mgr._z, mgr._z_ok = g["mgr_z"], g["mgr_ok"]
             if mgr.after_step(self.model.quant, self.opt):
                 for qz in self.model._quantizers():
                     if qz._prepared is not None:
@@ -152,9 +168,7 @@ class VQVAETrainer:
         static_tile, static_mask = tile, mask                      # the caller's buffers ARE the static inputs (kept alive by the graph record)
         if self.opt.lr_dev is None:
             self.opt.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
-        lr_host = torch.zeros(1, dtype=torch.float32).pin_memory()
-        lr_host.fill_(cosine_lr(self.step_idx, self.total_steps, self.lr, self.min_lr))
-        self.opt.lr_dev.copy_(lr_host)
+        self.opt.lr_dev.fill_(cosine_lr(self.step_idx, self.total_steps, self.lr, self.min_lr))
         mgr = getattr(self.model, "codebook_manager", None)
         saved_after = None
         if mgr is not None and hasattr(mgr, "after_step"):         # the revival pass is scheduled by the host: not part of the body
@@ -174,11 +188,12 @@ class VQVAETrainer:
                 out = self._step_body(static_tile, static_mask)
             if getattr(self, "_graph_pool", None) is None:
                 self._graph_pool = graph.pool()
+            mgr_z, mgr_ok = (getattr(mgr, "_z", None), getattr(mgr, "_z_ok", None)) if mgr is not None else (None, None)
             self._restore(snap)
         finally:
             if saved_after is not None:
                 mgr.after_step = saved_after
-        return dict(key=key, graph=graph, tile=static_tile, mask=static_mask, out=out, lr_host=lr_host)
+        return dict(key=key, graph=graph, tile=static_tile, mask=static_mask, out=out, mgr_z=mgr_z, mgr_ok=mgr_ok)
 
     def _snapshot(self):
         m, o = self.model, self.opt
@@ -186,8 +201,10 @@ class VQVAETrainer:
                   counters=o.counters.clone(), step_count=o.step_count, lag=list(o.lag),
                   buffers=[b.detach().clone() for b in m.buffers()])
         mgr = getattr(m, "codebook_manager", None)
-        if mgr is not None and getattr(mgr, "window", None) is not None:
-            st["window"] = mgr.window.clone()
+        if mgr is not None and hasattr(mgr, "window"):
+            # (None before the manager's first update: the warm-up steps allocate it, and it must come back EMPTY)
+            st["window"] = None if mgr.window is None else mgr.window.clone()
+            st["revived"] = None if getattr(mgr, "revived", None) is None else mgr.revived.clone()
         return st
 
     def _restore(self, st):
@@ -206,8 +223,16 @@ class VQVAETrainer:
         o._key = None
         self._images_refresh()                                     # the weight images follow the restored parameters
         mgr = getattr(m, "codebook_manager", None)
-        if mgr is not None and "window" in st:
-            mgr.window.copy_(st["window"])
+        if mgr is not None and "window" in st and mgr.window is not None:
+            if st["window"] is None:
+                mgr.window.zero_()
+            else:
+                mgr.window.copy_(st["window"])
+            if getattr(mgr, "revived", None) is not None:
+                if st["revived"] is None:
+                    mgr.revived.zero_()
+                else:
+                    mgr.revived.copy_(st["revived"])
         if hasattr(m, "_quantizers"):
             for qz in m._quantizers():
                 qz.drop_ema()

@@ -41,7 +41,10 @@ def extract_at_locations(feature: torch.Tensor, coords: torch.Tensor) -> torch.T
     """feature [C, H, W] (any strides), coords [N, 2] as (row, col) -> [N, C]."""
     if feature.dim() != 3 or coords.dim() != 2 or coords.shape[1] != 2:
         raise ValueError("extract_at_locations: feature must be [C, H, W] and coords [N, 2]")
-    coords = coords.to(device=feature.device, dtype=torch.int64).contiguous()
+    coords = coords.to(device=feature.device, dtype=torch.int64)
+    _, h, w = feature.shape
+    coords = torch.stack([ops.sanitize_indices(coords[:, 0], h, "extract_at_locations: row"),
+                          ops.sanitize_indices(coords[:, 1], w, "extract_at_locations: col")], dim=1).contiguous()
     if feature.requires_grad:
         return _GatherFn.apply(feature, coords)
     return ops.gather_locations(feature, coords)
