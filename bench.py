@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-finite-check", action="store_true")
+    ap.add_argument("--no-collapsed-line", action="store_true", help="skip the secondary timing on the randn (collapsing) codebook")
     ap.add_argument("--serial-streams", action="store_true",
                     help="run the phase branch on the main stream (per-kernel profiling: no overlap between the two branches)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -53,6 +54,9 @@ def parse():
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the train step from a captured hipGraph (VQVAETrainer.step_graphed); auto: whenever the trainer supports it")
     ap.add_argument("--phase-codebook", type=int, default=0, help="second codebook on z_phase (BASELINE configs[4])")
+    ap.add_argument("--codebook-init", default="data", choices=["data", "randn"],
+                    help="data: codes start on encoder outputs of the first batch (every code in use: the timed steps run a live codebook); "
+                         "randn: E = randn(K, d), which collapses to a few codes on randn tiles (reported as the secondary line either way)")
     ap.add_argument("--extra", action="store_true",
                     help="N=1 only: also time BASELINE configs[3] (K=8192, d=128), configs[4] at one GPU (T=10, 64x64, two codebooks of 1024) "
                          "and the float32 parity mode of configs[1]; reported under \"extra\" (secondary lines, never `value`)")
@@ -123,16 +127,21 @@ def cpu_baseline(args):
                       f"median; value = batches of 8 tiles, batches of 1 tile: {rates[1]:.2f} tiles/s; {total:.1f} s timed"}
 
 
-def build_trainer(args, dev, dtype, codebook, emb_dim, phase_codebook=0, serial=False):
+def build_trainer(args, dev, dtype, codebook, emb_dim, phase_codebook=0, serial=False, init_tile=None):
+    """init_tile: a batch of tiles -> the codebook(s) start on encoder outputs drawn from it (VQVAE.init_codebook_from_tiles: every
+    code is in use, perplexity of the order of K -- a codebook in the regime training aims for); None -> E = randn(K, d), seed 7
+    (SURVEY.md 8d's argmin-parity codebook), which on randn tiles collapses to a handful of codes within a few steps."""
     from frl_hip.models import VQVAE
     from frl_hip.training.trainer import VQVAETrainer
     torch.manual_seed(0)
     model = VQVAE(in_features=args.features, codebook_size=codebook, emb_dim=emb_dim, beta=0.25, phase_codebook_size=phase_codebook,
                   type_encoder_dropout=0.0, phase_tcn_dropout=0.0, compute_dtype=dtype).to(dev)
-    with torch.no_grad():   # well-separated codebook so that all codes are used
+    with torch.no_grad():
         model.quant.codebook.copy_(torch.randn(codebook, emb_dim, generator=torch.Generator().manual_seed(7)))
         if phase_codebook:
             model.quant_phase.codebook.copy_(torch.randn(phase_codebook, model.z_phase_dim, generator=torch.Generator().manual_seed(8)))
+    if init_tile is not None:
+        model.init_codebook_from_tiles(init_tile, seed=7)
     model.concurrent_phase = not serial
     trainer = VQVAETrainer(model, lr=1e-4, total_steps=10000, check_finite=not args.no_finite_check, fused_optimizer=not args.torch_optimizer)
     return model, trainer
@@ -202,8 +211,9 @@ def main():
     from frl_hip.data import SyntheticTileStream
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model, trainer = build_trainer(args, dev, dtype, args.codebook, args.emb_dim, args.phase_codebook, args.serial_streams)
     stream = SyntheticTileStream(args.batch, args.time, args.size, args.features, device=dev, dtype=dtype, seed=1234 + rank)
+    init_tile = None if args.codebook_init == "randn" else stream.tiles[0]
+    model, trainer = build_trainer(args, dev, dtype, args.codebook, args.emb_dim, args.phase_codebook, args.serial_streams, init_tile)
 
     def barrier():
         torch.cuda.synchronize()
@@ -258,7 +268,10 @@ def main():
                                f"K={args.codebook}, d={args.emb_dim}, dropout 0.0",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}", "finite_check": not args.no_finite_check,
                    "launch": "hipGraph replay of the whole step (one graph per tile-pool buffer)" if graphed else "eager (one launch per kernel)",
-                   "loss": round(float(last["loss"].detach()), 5), "perplexity": round(float(last["perplexity"]), 2)},
+                   "loss": round(float(last["loss"].detach()), 5), "perplexity": round(float(last["perplexity"]), 2),
+                   "codebook_init": "encoder outputs of the first batch (VQVAE.init_codebook_from_tiles)" if args.codebook_init == "data"
+                   else "randn(K, d), seed 7",
+                   "vq_rows_reevaluated": round(float(last["vq_stats"][2]) / (args.batch * args.size * args.size), 5)},
         "host_ms_per_step": round(1e3 * t_host / args.steps, 3),
         "rank_ms_per_step": {"max": round(max(rank_ms), 3), "min": round(min(rank_ms), 3)},
         "backend": ("rccl" if args.backend == "nccl" else "gloo") if world > 1 else None, "rccl_ranks": rccl_ranks,
@@ -279,6 +292,8 @@ def main():
         out["vq_hbm"] = {"GB/s": round(vq_bytes / vq_ms / 1e6, 1), "frac": round(vq_bytes / vq_ms / 1e6 / HBM_PEAK_GBS, 4),
                          "ms": round(vq_ms, 4), "bytes": vq_bytes,
                          "note": "live HIP-event span of the whole frl_vq_assign_fwd call (every kernel the call launches)"}
+        out["vq_hbm"]["rows_reevaluated"] = out["config"]["vq_rows_reevaluated"]     # stats[2] / N of the last timed step
+        out["vq_hbm"]["perplexity"] = out["config"]["perplexity"]
         kv = [v for k, v in kern.items() if "vq_assign" in k]
         if kv:                                                # the L2/argmin kernel alone (library-side event pair around its launch)
             us = 1e3 * sum(ms for _, ms in kv) / sum(c for c, _ in kv)
@@ -320,6 +335,16 @@ def main():
         dom = max(ftime, key=lambda k: ftime[k][1])
         out["roofline"] = roofline_for(dom, ftime, args, model, n, s)
         args.steps = args.steps_timed
+    if world == 1 and args.codebook_init == "data" and not args.no_collapsed_line:
+        # secondary line (never `value`): the same step on the randn codebook, whose assignment collapses to a few codes -- the regime
+        # the earlier rounds' lines were measured in (the VQ kernel's re-evaluation share and histogram contention depend on it)
+        m2, t2 = build_trainer(args, dev, dtype, args.codebook, args.emb_dim, args.phase_codebook, args.serial_streams, None)
+        dt2, _, last2 = timed_steps(t2, stream, 20, 25, barrier, graphed)
+        out["collapsed_codebook"] = {"codebook_init": "randn(K, d), seed 7", "ms_per_step": round(1e3 * dt2 / 20, 3),
+                                     "tiles/s": round(args.batch * 20 / dt2, 1), "steps": 20, "warmup": 25,
+                                     "perplexity": round(float(last2["perplexity"]), 2),
+                                     "vq_rows_reevaluated": round(float(last2["vq_stats"][2]) / (args.batch * args.size * args.size), 5)}
+        del m2, t2, last2
     if world == 1 and args.extra:
         del trainer, stream, last
         out["extra"] = extra_lines(args, dev, barrier)

@@ -290,7 +290,7 @@ class ChannelScaleFn(Function):
 
 
 class VQFn(Function):
-    """(z [N,d], codebook [K,d]) -> (z_q [straight-through], L_codebook, L_commit, perplexity, idx, counts).
+    """(z [N,d], codebook [K,d]) -> (z_q [straight-through], L_codebook, L_commit, perplexity, idx, counts, stats).
 
     L_codebook = mean((sg[z] - z_q)^2) and L_commit = mean((z - sg[z_q])^2) are numerically equal in the forward;
     they are separate outputs so that autograd routes their upstream gradients to the codebook and to z respectively.
@@ -306,11 +306,12 @@ class VQFn(Function):
         ctx.mark_non_differentiable(idx, counts)
         # stats = {sum ||z - z_q||^2, perplexity, rows re-evaluated, mean squared error}: the two loss terms are numerically equal
         mse = stats.narrow(0, 3, 1).reshape(())
-        return zq, mse, mse.clone(), stats.narrow(0, 1, 1).reshape(()), idx, counts
+        ctx.mark_non_differentiable(stats)
+        return zq, mse, mse.clone(), stats.narrow(0, 1, 1).reshape(()), idx, counts, stats
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g_zq, g_cb, g_cm, g_perp, g_idx, g_counts):
+    def backward(ctx, g_zq, g_cb, g_cm, g_perp, g_idx, g_counts, g_stats):
         z, codebook, idx, counts, zq = ctx.saved_tensors
         if g_cm is not None and g_cb is not None:
             gs = torch.stack([g_cm.reshape(()).float(), g_cb.reshape(()).float()])      # one launch

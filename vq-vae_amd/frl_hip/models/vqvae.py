@@ -39,6 +39,7 @@ class VectorQuantizer(nn.Module):
             self.register_buffer("ema_count", torch.zeros(codebook_size))
             self.register_buffer("ema_sum", self.codebook.detach().clone())
         self.last_counts: Optional[torch.Tensor] = None
+        self.last_stats: Optional[torch.Tensor] = None
         # A trainer that guards the step against a non-finite loss sets defer_ema: the statistics of the batch are then kept until
         # apply_ema(ok) -- after the loss is known -- instead of being folded into the running averages inside forward().
         self.defer_ema = False
@@ -58,8 +59,9 @@ class VectorQuantizer(nn.Module):
 
     def forward(self, z_rows: torch.Tensor):
         """z_rows [N, d] -> (z_q [N,d] with straight-through gradient, vq_loss, perplexity, idx int32 [N])."""
-        zq, l_cb, l_cm, perp, idx, counts = Fh.VQFn.apply(z_rows, self.codebook, self.prepared(z_rows.dtype, z_rows.shape[0]))
+        zq, l_cb, l_cm, perp, idx, counts, stats = Fh.VQFn.apply(z_rows, self.codebook, self.prepared(z_rows.dtype, z_rows.shape[0]))
         self.last_counts = counts
+        self.last_stats = stats          # f32 [4]: sum ||z - z_q||^2, perplexity, rows whose arg-min was re-evaluated exactly, mean squared error
         if self.quantizer == "ema":
             vq_loss = Fh.scalar_combine([l_cm], [self.beta])[0]
             if self.training:
@@ -220,7 +222,7 @@ class VQVAE(RepresentationModel):
         zq, vq_loss, perp, idx = self.quant(z_type.reshape(-1, d))
         tmask = mask.amin(dim=1) if (mask is not None and mask.dim() == 4) else mask
         l_type, xhat_type = self._decode_loss(self.decoder_type, zq.reshape(b, hh, ww, d), x_type, tmask, return_recon)
-        out = dict(z_type=z_type, gate=gate, idx=idx, vq_loss=vq_loss, perplexity=perp, l_type=l_type)
+        out = dict(z_type=z_type, gate=gate, idx=idx, vq_loss=vq_loss, perplexity=perp, l_type=l_type, vq_stats=self.quant.last_stats)
         if xhat_type is not None:
             out["xhat_type"] = xhat_type
         terms = [(l_type, self.lambda_recon), (vq_loss, self.lambda_vq)]
@@ -244,6 +246,37 @@ class VQVAE(RepresentationModel):
             if not self.defer_codebook_hooks:
                 self.commit_codebook_hooks()
         return out
+
+    @torch.no_grad()
+    def init_codebook_from_tiles(self, tile: torch.Tensor, seed: int = 0) -> None:
+        """Data-dependent codebook initialisation: every code starts on the encoder output of a pixel drawn (seeded, without
+        replacement) from `tile` [B,T,H,W,F] -- the usual remedy for the index collapse of a codebook initialised far from the
+        encoder's output distribution (the legacy trainer pairs the model with a CodebookManager for the same reason,
+        scripts/train_vqvae.py:196-198; the manager re-seeds dead codes with encoder rows in exactly this way during training).
+        The phase codebook, when present, is initialised from z_phase rows likewise.  Runs the HIP forward path."""
+        self._require_gpu(tile)
+        tile = self._rows(tile)
+        was_training = self.training
+        self.eval()
+        try:
+            z_type = self.forward_nhwc(ops.mean_time(tile))
+            gen = torch.Generator(device="cpu").manual_seed(int(seed))
+
+            def draw(rows: torch.Tensor, q: "VectorQuantizer"):
+                rows = rows.reshape(-1, rows.shape[-1]).float()
+                if rows.shape[0] < q.codebook_size:
+                    raise ValueError(f"init_codebook_from_tiles: {rows.shape[0]} encoder rows for {q.codebook_size} codes")
+                pick = torch.randperm(rows.shape[0], generator=gen)[:q.codebook_size].to(rows.device)
+                q.codebook.copy_(rows[pick])
+                if q.quantizer == "ema":
+                    q.ema_sum.copy_(q.codebook)
+                    q.ema_count.fill_(1.0)
+
+            draw(z_type, self.quant)
+            if hasattr(self, "quant_phase"):
+                draw(self.forward_phase_nhwc(tile, z_type), self.quant_phase)
+        finally:
+            self.train(was_training)
 
     def _quantizers(self):
         return [q for q in (getattr(self, "quant", None), getattr(self, "quant_phase", None)) if q is not None]
