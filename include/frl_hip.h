@@ -146,6 +146,24 @@ int frl_edge_smooth_stencil_fwd(const void* x, const void* a_logit, const void* 
 int frl_edge_smooth_stencil_bwd(const void* d_smoothed, const void* x, const void* a_soft, const void* b_soft, void* dx,
                                 void* da_logit, void* db_logit, const void* dx_add /* optional: added to dx in the store */, int B, int H,
                                 int W, int C, int R, int coarse_dilation, int dtype, frl_stream_t stream);
+/* Fused mixing heads + softmaxes + directional bank for the hot configuration (bf16, C = 64, 64 hidden features, rank 4; replaces
+ * mix_head_A / mix_head_B (nn.Conv2d 1x1, spatial.py:262-263), the two softmaxes (:300-307) and the bank + mix (:314-331) in one launch;
+ * the [P,32] / [P,256] logits and their soft-maxed copies never reach memory).  feat = relu(mix_backbone(cat[dx,dy])) [B][H][W][64];
+ * wa [32][64], ba [32], wb [256][64], bb [256] float32 with output channels k*R+r resp. c*R+r. */
+int frl_smooth_heads_supported(int C, int hidden, int rank, int dtype);
+size_t frl_smooth_heads_workspace_bytes(int64_t npix);
+int frl_smooth_heads_fwd(const void* x, const void* feat, const float* wa, const float* ba, const float* wb, const float* bb,
+                         void* smoothed, void* residual, int B, int H, int W, int coarse_dilation, void* ws, size_t ws_bytes,
+                         frl_stream_t stream);
+/* backward: d_smoothed already carries the residual path (d smoothed - d residual); dx_add (optional) is added to dx.  The heads are
+ * recomputed from feat; outputs dx, dfeat [P][64] (bf16) and the four head parameter gradients (float32).  scratch: exchange tensors of
+ * the two launches (u = ds * softmax B [P][256], softmax A [P][32], bf16), frl_smooth_heads_bwd_scratch_bytes(npix) bytes. */
+size_t frl_smooth_heads_bwd_scratch_bytes(int64_t npix);
+int frl_smooth_heads_force_gather(int on);     /* test hook: d x of the backward by the gather kernel instead of the LDS-tiled one; returns the previous setting */
+int frl_smooth_heads_bwd(const void* d_smoothed, const void* x, const void* feat, const float* wa, const float* ba, const float* wb,
+                         const float* bb, const void* dx_add, void* dx, void* dfeat, float* dwa, float* dba, float* dwb, float* dbb,
+                         void* scratch, size_t scratch_bytes, int B, int H, int W, int coarse_dilation, void* ws, size_t ws_bytes,
+                         frl_stream_t stream);
 /* out = smoothed + max(gate_raw, min_gate) * residual (spatial.py:333-335); n = element count */
 int frl_gate_blend_fwd(const void* smoothed, const void* residual, const void* gate_raw, float min_gate, void* out,
                        void* gate_out, int64_t n, int dtype, frl_stream_t stream);

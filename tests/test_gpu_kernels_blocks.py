@@ -190,6 +190,58 @@ def test_edge_smooth_stencil(dtype, atol, wtol, B, H, W, C, R):
     assert torch.equal(da2, da) and torch.equal(db2, db)
 
 
+@pytest.mark.parametrize("B,H,W,dil", [(2, 32, 32, 3), (1, 16, 24, 3), (3, 9, 13, 2), (1, 5, 7, 3), (2, 20, 16, 3), (1, 12, 64, 2)])
+def test_fused_mixing_heads_softmax_bank_match_float64(B, H, W, dil):
+    """csrc/smooth_fused.hip (bf16, 64 channels, 64 hidden features, rank 4): the two 1x1 heads, both softmaxes and the directional bank
+    in one forward launch, and the backward pair (heads recomputed; d feat, d x, head parameter gradients produced in-kernel, no [P,288]
+    tensor anywhere) against float64 autograd of spatial.py:300-331 on the same bf16-rounded inputs.  Shapes: the hot 32x32 tiles,
+    pixel counts that are not multiples of the 16 / 128-pixel work items, images narrower than the coarse stencil, dilation 2; widths
+    that take the LDS-tiled d x kernel (multiples of 16; 20 rows = a ragged last band) and widths that take its gather form."""
+    from frl_hip import ops
+    C, HID, R = 64, 64, 4
+    g = torch.Generator().manual_seed(H * W + dil)
+    dt = torch.bfloat16
+    x = q(torch.randn(B, C, H, W, generator=g), dt).requires_grad_(True)
+    feat = q(torch.randn(B, HID, H, W, generator=g).clamp_min(0.0), dt).requires_grad_(True)
+    wa = (torch.randn(8 * R, HID, generator=g) * 0.3)
+    ba = torch.randn(8 * R, generator=g) * 0.2
+    wb = (torch.randn(C * R, HID, generator=g) * 0.3)
+    bb = torch.randn(C * R, generator=g) * 0.2
+    # the kernels round the weights to bf16 for the matrix cores: the float64 reference uses the same rounded values
+    wa64, wb64 = q(wa, dt).requires_grad_(True), q(wb, dt).requires_grad_(True)
+    ba64, bb64 = ba.double().requires_grad_(True), bb.double().requires_grad_(True)
+    al = F.conv2d(feat, wa64.reshape(8 * R, HID, 1, 1), ba64)
+    bl = F.conv2d(feat, wb64.reshape(C * R, HID, 1, 1), bb64)
+    sm, res = _smooth_ref(x, al, bl, R, dil)
+    xd, fd = nhwc(x.detach()).to(dt).to(DEV), nhwc(feat.detach()).to(dt).to(DEV)
+    wad, bad, wbd, bbd = (t.float().to(DEV).contiguous() for t in (wa64.detach(), ba, wb64.detach(), bb))
+    assert ops.smooth_heads_supported(xd, HID, R, wad, bad, wbd, bbd)
+    smd, resd = ops.smooth_heads_fwd(xd, fd, wad, bad, wbd, bbd, dil)
+    assert rel_err(smd.float(), nhwc(sm.detach())) <= 8e-3
+    assert rel_err(resd.float(), nhwc(res.detach())) <= 8e-3
+    ds = q(torch.randn(B, C, H, W, generator=g), dt)
+    add = q(torch.randn(B, C, H, W, generator=g), dt)
+    sm.backward(ds)
+    dx, dfeat, dwa, dba, dwb, dbb = ops.smooth_heads_bwd(nhwc(ds).to(dt).to(DEV), xd, fd, wad, bad, wbd, bbd, dil, dx_add=nhwc(add).to(dt).to(DEV))
+    assert rel_err(dx.float(), nhwc(x.grad + add)) <= 1.5e-2
+    assert rel_err(dfeat.float(), nhwc(feat.grad)) <= 3e-2
+    for got, ref in ((dwa, wa64.grad), (dba, ba64.grad), (dwb, wb64.grad), (dbb, bb64.grad)):
+        assert rel_err(got, ref) <= 3e-2
+    dx0 = ops.smooth_heads_bwd(nhwc(ds).to(dt).to(DEV), xd, fd, wad, bad, wbd, bbd, dil)[0]
+    assert rel_err(dx0.float(), nhwc(x.grad)) <= 1.5e-2
+    # the two forms of the d x kernel (LDS tiles / L2 gathers) add the same terms, associated differently: equal to a bf16 ulp
+    from frl_hip import _lib
+    was = _lib.load().frl_smooth_heads_force_gather(1)
+    try:
+        dx1 = ops.smooth_heads_bwd(nhwc(ds).to(dt).to(DEV), xd, fd, wad, bad, wbd, bbd, dil)[0]
+    finally:
+        _lib.load().frl_smooth_heads_force_gather(was)
+    assert rel_err(dx1.float(), dx0.float().cpu()) <= 8e-3 and rel_err(dx1.float(), nhwc(x.grad)) <= 1.5e-2
+    # not the hot configuration: the callers keep the modular kernels
+    assert not ops.smooth_heads_supported(xd.float(), HID, R, wad, bad, wbd, bbd)
+    assert not ops.smooth_heads_supported(xd, HID, R, wad, None, wbd, bbd)
+
+
 @pytest.mark.parametrize("dtype,atol,wtol", MODES)
 @pytest.mark.parametrize("B,T,HW,cin,cout,G,dil", [(2, 5, 64, 8, 8, 4, 1), (2, 5, 64, 8, 8, 4, 4), (1, 5, 1024, 64, 64, 8, 2), (3, 10, 50, 64, 64, 8, 4),
                                                    (1, 5, 37, 16, 8, 4, 1), (1, 15, 16, 64, 64, 8, 4), (1, 5, 32, 12, 64, 8, 2)])
@@ -570,8 +622,8 @@ def test_backward_epilogue_sums_match_separate_launches(dtype, tol):
 @pytest.mark.parametrize("B,H,W,C,hidden", [(2, 32, 32, 64, 64), (1, 9, 13, 16, 24)])
 def test_spatial_smoothing_block_as_one_autograd_node_matches_the_modular_chain(dtype, tol, B, H, W, C, hidden):
     """EdgeAwareSmoothingConv2D: fuse=True (Fh.SpatialSmoothFn, gradient sums in kernel epilogues) against fuse=False (one autograd
-    node per kernel, sums by autograd).  The forward kernels are the same launches, so outputs are bit-equal; gradients agree to the
-    rounding of the intermediate sums."""
+    node per kernel, sums by autograd).  Outside the hot configuration the forward kernels are the same launches, so outputs are
+    bit-equal; gradients agree to the rounding of the intermediate sums."""
     from frl_hip.models.blocks import EdgeAwareSmoothingConv2D
     torch.manual_seed(5 + C)
     m = EdgeAwareSmoothingConv2D(C, gate_hidden=hidden).to(DEV)
@@ -580,19 +632,41 @@ def test_spatial_smoothing_block_as_one_autograd_node_matches_the_modular_chain(
     dout = torch.randn(B, H, W, C, generator=torch.Generator().manual_seed(10)).to(dtype).to(DEV)
     dgate = (torch.randn(B, H, W, C, generator=torch.Generator().manual_seed(11)) * 0.3).to(dtype).to(DEV)
     res = {}
-    for fuse in (False, True):
+
+    def run(fuse, dt):
         m.fuse = fuse
         m.zero_grad(set_to_none=True)
-        x = x0.clone().requires_grad_(True)
+        x = x0.to(dt).clone().requires_grad_(True)
         out, gate = m(x, return_gate=True)
-        torch.autograd.backward([out, gate], [dout, dgate])
-        res[fuse] = (out.detach(), gate.detach(), x.grad.detach().float(), {n: p.grad.detach().clone() for n, p in m.named_parameters()})
-    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
-    gx_f, gx_m = res[True][2], res[False][2]
-    assert (gx_f - gx_m).abs().max().item() <= tol * gx_m.abs().max().item()
-    for n, gm in res[False][3].items():
-        gf = res[True][3][n]
-        assert (gf - gm).abs().max().item() <= tol * max(gm.abs().max().item(), 1e-6), n
+        torch.autograd.backward([out, gate], [dout.to(dt), dgate.to(dt)])
+        return (out.detach().float(), gate.detach().float(), x.grad.detach().float(), {n: p.grad.detach().clone() for n, p in m.named_parameters()})
+
+    for fuse in (False, True):
+        res[fuse] = run(fuse, dtype)
+    hot = dtype == torch.bfloat16 and C == 64 and hidden == 64
+    if hot:
+        # Hot configuration: the fused node runs heads + softmaxes + bank as one kernel per direction (float32 logits that never leave
+        # the registers; heads recomputed in the backward), the modular chain rounds logits, soft-maxed maps and their gradients to bf16
+        # in between.  Both are bf16 evaluations of the same function: each is held against the float32 evaluation of the modular chain on
+        # the same (bf16-representable) inputs, and the fused node may not be further from it than 1.5 x the modular chain's own distance (both sit at 4-5 % on the gate-net bias sums).
+        ref = run(False, torch.float32)
+
+        def err(a, b):
+            return (a.float() - b.float()).abs().max().item() / max(b.float().abs().max().item(), 1e-6)
+
+        for i, name in ((0, "out"), (1, "gate"), (2, "dx")):
+            ef, em = err(res[True][i], ref[i]), err(res[False][i], ref[i])
+            assert ef <= max(1.5 * em, 1e-2) and ef <= tol, (name, ef, em)
+        for n, gr in ref[3].items():
+            ef, em = err(res[True][3][n], gr), err(res[False][3][n], gr)
+            assert ef <= max(1.5 * em, 3e-2) and ef <= 2.5 * tol, (n, ef, em)
+    else:
+        assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+        gx_f, gx_m = res[True][2], res[False][2]
+        assert (gx_f - gx_m).abs().max().item() <= tol * gx_m.abs().max().item()
+        for n, gm in res[False][3].items():
+            gf = res[True][3][n]
+            assert (gf - gm).abs().max().item() <= tol * max(gm.abs().max().item(), 1e-6), n
     # the gate output may carry no gradient at all (return_gate=False callers)
     m.fuse = True
     x = x0.clone().requires_grad_(True)

@@ -18,7 +18,7 @@ __device__ __forceinline__ void pk_frag_pw(const FrlPackJob& j, int i) {
   const int s = fs % j.NF, mb = fs / j.NF;
   const int r = lane & 15, kc = lane >> 4;
   const int qo = 4 * j.MB;
-  const int oc = qo * (r >> 2) + 4 * mb + (r & 3);
+  const int oc = j.kind == FRL_PACK_PW_REP ? 4 * mb + (r & 3) : qo * (r >> 2) + 4 * mb + (r & 3);
   if (j.dtype == FRL_BF16) {
     const int q = j.NF * 8;
     bf16x8 v;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void frl_pack_jobs_kernel(const FrlPackJob* __
   const FrlPackJob j = jobs[bk.x];
   const int end = (bk.y + PK_FRAGS_PER_BLOCK) < j.nfrag ? (bk.y + PK_FRAGS_PER_BLOCK) : j.nfrag;
   for (int i = bk.y + threadIdx.x; i < end; i += 256) {
-    if (j.kind == FRL_PACK_PW) pk_frag_pw(j, i); else pk_frag_c3(j, i);
+    if (j.kind == FRL_PACK_C3) pk_frag_c3(j, i); else pk_frag_pw(j, i);
   }
 }
 

@@ -94,6 +94,12 @@ SIGNATURES = {
     "frl_sobel_bwd_add": (c_int, [P, P, P, I, I, I, I, I, P]),
     "frl_edge_smooth_stencil_fwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "frl_edge_smooth_stencil_bwd": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "frl_smooth_heads_supported": (c_int, [I, I, I, I]),
+    "frl_smooth_heads_workspace_bytes": (S, [L]),
+    "frl_smooth_heads_bwd_scratch_bytes": (S, [L]),
+    "frl_smooth_heads_force_gather": (c_int, [I]),
+    "frl_smooth_heads_fwd": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, P, S, P]),
+    "frl_smooth_heads_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, S, I, I, I, I, P, S, P]),
     "frl_tcn_block_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, F, I, P, S, P]),
     "frl_tcn_block_bwd_data": (c_int, [P, P, P, P, P, L, I, I, I, I, I, I, P, S, P]),
     "frl_tcn_block_bwd_workspace_bytes": (S, [L, I]),

@@ -191,22 +191,31 @@ class SpatialSmoothFn(Function):
     def forward(ctx, x, w_mb, b_mb, w_a, b_a, w_b, b_b, w_g0, b_g0, w_g2, b_g2, rank, dil, min_gate):
         g = ops.sobel_fwd(x)
         feat = ops.conv3x3_fwd(g, w_mb, b_mb, ACT_RELU)
-        a_logit = ops.conv1x1_fwd(feat, w_a, b_a, ACT_NONE)
-        b_logit = ops.conv1x1_fwd(feat, w_b, b_b, ACT_NONE)
-        sm, res, a_soft, b_soft = ops.edge_smooth_fwd(x, a_logit, b_logit, rank, dil)
+        # hot configuration: heads + softmaxes + bank in ONE kernel, nothing of the [P,288] logits reaches memory (csrc/smooth_fused.hip);
+        # the backward recomputes the heads from feat
+        fused_heads = ops.smooth_heads_supported(x, feat.shape[-1], rank, w_a, b_a, w_b, b_b)
+        if fused_heads:
+            sm, res = ops.smooth_heads_fwd(x, feat, w_a, b_a, w_b, b_b, dil)
+            a_soft = b_soft = None
+        else:
+            a_logit = ops.conv1x1_fwd(feat, w_a, b_a, ACT_NONE)
+            b_logit = ops.conv1x1_fwd(feat, w_b, b_b, ACT_NONE)
+            sm, res, a_soft, b_soft = ops.edge_smooth_fwd(x, a_logit, b_logit, rank, dil)
         g1 = ops.conv3x3_fwd(res, w_g0, b_g0, ACT_RELU)
         gate_raw = ops.conv3x3_fwd(g1, w_g2, b_g2, ACT_SIGMOID)
         out, gate = ops.gate_blend_fwd(sm, res, gate_raw, min_gate)
         ctx.cfg = (rank, dil, min_gate)
         ctx.has_bias = tuple(b is not None for b in (b_mb, b_a, b_b, b_g0, b_g2))
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(x, g, feat, a_soft, b_soft, res, g1, gate_raw, w_mb, w_a, w_b, w_g0, w_g2)
+        ctx.fused_heads = fused_heads
+        ctx.save_for_backward(x, g, feat, a_soft, b_soft, res, g1, gate_raw, w_mb, w_a, w_b, w_g0, w_g2, b_a if fused_heads else None,
+                              b_b if fused_heads else None)
         return out, gate
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout, dgate):
-        x, g, feat, a_soft, b_soft, res, g1, gate_raw, w_mb, w_a, w_b, w_g0, w_g2 = ctx.saved_tensors
+        x, g, feat, a_soft, b_soft, res, g1, gate_raw, w_mb, w_a, w_b, w_g0, w_g2, b_a, b_b = ctx.saved_tensors
         rank, dil, min_gate = ctx.cfg
         dout = torch.zeros_like(res) if dout is None else _c(dout)
         dres, dgraw = ops.gate_blend_bwd(dout, _c(dgate), res, gate_raw, min_gate)
@@ -215,10 +224,13 @@ class SpatialSmoothFn(Function):
         # residual: blend term + gate-net term in one store; d(smoothed) - d(residual) (residual = x - smoothed) as the second output
         dres_tot, d_tot = ops.conv3x3_bwd_data(dg1, w_g0, g1, ACT_RELU, add=dres, sub_from=dout)
         dw_g0, db_g0 = ops.conv3x3_bwd_weight(dg1, res, g1, ACT_RELU)
-        dx, da, db = ops.edge_smooth_bwd(d_tot, x, a_soft, b_soft, rank, dil, dx_add=dres_tot)
-        dfeat = ops.conv1x1_bwd_data(db, w_b, None, ACT_NONE, add=ops.conv1x1_bwd_data(da, w_a, None, ACT_NONE))
-        dw_a, db_a = ops.conv1x1_bwd_weight(da, feat, None, ACT_NONE, want_bias=ctx.has_bias[1])
-        dw_b, db_b = ops.conv1x1_bwd_weight(db, feat, None, ACT_NONE, want_bias=ctx.has_bias[2])
+        if ctx.fused_heads:
+            dx, dfeat, dw_a, db_a, dw_b, db_b = ops.smooth_heads_bwd(d_tot, x, feat, w_a, b_a, w_b, b_b, dil, dx_add=dres_tot)
+        else:
+            dx, da, db = ops.edge_smooth_bwd(d_tot, x, a_soft, b_soft, rank, dil, dx_add=dres_tot)
+            dfeat = ops.conv1x1_bwd_data(db, w_b, None, ACT_NONE, add=ops.conv1x1_bwd_data(da, w_a, None, ACT_NONE))
+            dw_a, db_a = ops.conv1x1_bwd_weight(da, feat, None, ACT_NONE, want_bias=ctx.has_bias[1])
+            dw_b, db_b = ops.conv1x1_bwd_weight(db, feat, None, ACT_NONE, want_bias=ctx.has_bias[2])
         dw_mb, db_mb = ops.conv3x3_bwd_weight(dfeat, g, feat, ACT_RELU)
         if ctx.needs_input_grad[0]:
             dx = ops.sobel_bwd(ops.conv3x3_bwd_data(dfeat, w_mb, feat, ACT_RELU), add=dx)

@@ -705,6 +705,52 @@ def edge_smooth_bwd(d_smoothed, x, a_soft, b_soft, rank: int, coarse_dilation: i
     return dx, da, db
 
 
+def smooth_heads_supported(x: torch.Tensor, hidden: int, rank: int, wa, ba, wb, bb) -> bool:
+    """True when the two mixing heads, their softmaxes and the directional bank run as ONE kernel per direction (csrc/smooth_fused.hip):
+    bf16 rows of 64 channels, 64 hidden features, rank 4, both heads with a bias."""
+    if ba is None or bb is None or x.dim() != 4 or not x.is_cuda:
+        return False
+    if tuple(wa.shape[:2]) != (8 * rank, hidden) or tuple(wb.shape[:2]) != (x.shape[-1] * rank, hidden):
+        return False
+    return bool(_lib.load().frl_smooth_heads_supported(x.shape[-1], hidden, rank, _dt(x)))
+
+
+@_timed("smooth_heads_fwd")
+def smooth_heads_fwd(x, feat, wa, ba, wb, bb, coarse_dilation: int):
+    """x, feat [B,H,W,64] bf16; wa [32,64(,1,1)], wb [256,64(,1,1)] f32 -> (smoothed, residual)."""
+    b, h, w, c = x.shape
+    _chk_rows(x, c, "smooth_heads_fwd.x")
+    _chk_like(feat, x, "smooth_heads_fwd.feat")
+    lib = _lib.load()
+    ws = workspace(lib.frl_smooth_heads_workspace_bytes(b * h * w), x.device)
+    sm, res = torch.empty_like(x), torch.empty_like(x)
+    check(lib.frl_smooth_heads_fwd(_p(x), _p(feat), _p(_f32(wa, "wa")), _p(_f32(ba, "ba")), _p(_f32(wb, "wb")), _p(_f32(bb, "bb")), _p(sm), _p(res),
+                                   b, h, w, coarse_dilation, _p(ws), ws.numel(), _stream()), "frl_smooth_heads_fwd")
+    return sm, res
+
+
+@_timed("smooth_heads_bwd")
+def smooth_heads_bwd(d_smoothed, x, feat, wa, ba, wb, bb, coarse_dilation: int, dx_add: Optional[torch.Tensor] = None):
+    """-> (dx, dfeat [B,H,W,64] bf16, dwa, dba, dwb, dbb f32).  d_smoothed: gradient w.r.t. `smoothed` with the residual path folded in
+    (d smoothed - d residual); dx_add: added to dx inside the kernel's store."""
+    b, h, w, c = x.shape
+    for t, n in ((d_smoothed, "d_smoothed"), (feat, "feat")):
+        _chk_like(t, x, f"smooth_heads_bwd.{n}")
+    if dx_add is not None:
+        _chk_like(dx_add, x, "smooth_heads_bwd.dx_add")
+    lib = _lib.load()
+    npix = b * h * w
+    ws = workspace(lib.frl_smooth_heads_workspace_bytes(npix), x.device)
+    scratch = torch.empty(lib.frl_smooth_heads_bwd_scratch_bytes(npix), dtype=torch.uint8, device=x.device)
+    dx, dfeat = torch.empty_like(x), torch.empty_like(feat)
+    dwa, dwb = torch.empty(wa.shape, dtype=torch.float32, device=x.device), torch.empty(wb.shape, dtype=torch.float32, device=x.device)
+    dba, dbb = torch.empty_like(ba), torch.empty_like(bb)
+    check(lib.frl_smooth_heads_bwd(_p(d_smoothed), _p(x), _p(feat), _p(_f32(wa, "wa")), _p(_f32(ba, "ba")), _p(_f32(wb, "wb")), _p(_f32(bb, "bb")),
+                                   _p(dx_add), _p(dx), _p(dfeat), _p(dwa), _p(dba), _p(dwb), _p(dbb), _p(scratch), scratch.numel(),
+                                   b, h, w, coarse_dilation, _p(ws), ws.numel(), _stream()), "frl_smooth_heads_bwd")
+    return dx, dfeat, dwa, dba, dwb, dbb
+
+
 # ----------------------------------------------------------------------------------------------
 # fused TCN block (csrc/tcn_fwd.hip, tcn_bwd.hip); x [B,T,HW..,Cin]
 # ----------------------------------------------------------------------------------------------
