@@ -164,6 +164,19 @@ int frl_smooth_heads_bwd(const void* d_smoothed, const void* x, const void* feat
                          const float* bb, const void* dx_add, void* dx, void* dfeat, float* dwa, float* dba, float* dwb, float* dbb,
                          void* scratch, size_t scratch_bytes, int B, int H, int W, int coarse_dilation, void* ws, size_t ws_bytes,
                          frl_stream_t stream);
+/* ---- FiLM conditioning of the phase path, fused (bf16, 64 conditioning channels, hidden 32, 12 target channels) ----------------------
+ * Replaces FiLMLayer.forward (frl/models/conditioning.py:82-102: two conv1x1 -> ReLU -> conv1x1 nets) and the modulation
+ * gamma * h + beta broadcast over T (frl/models/representation.py:369-372) with one launch per direction.  z_type [B][HW][64] is a
+ * stop-gradient input (representation.py:350-351); h, z, dz, dh [B][T][HW][12]; gamma, beta [B][HW][12]; w1* [32][64], w2* [12][32]. */
+int frl_film_fused_supported(int cond_dim, int hidden, int target_dim, int dtype);
+size_t frl_film_fused_workspace_bytes(void);
+int frl_film_fused_fwd(const void* z_type, const void* h, const float* w1g, const float* b1g, const float* w2g, const float* b2g,
+                       const float* w1b, const float* b1b, const float* w2b, const float* b2b, void* z, void* gamma, void* beta, int B,
+                       int T, int HW, void* ws, size_t ws_bytes, frl_stream_t stream);
+int frl_film_fused_bwd(const void* z_type, const void* h, const void* dz, const float* w1g, const float* b1g, const float* w2g,
+                       const float* b2g, const float* w1b, const float* b1b, const float* w2b, const float* b2b, void* dh, float* dw1g,
+                       float* db1g, float* dw2g, float* db2g, float* dw1b, float* db1b, float* dw2b, float* db2b, int B, int T, int HW,
+                       void* ws, size_t ws_bytes, frl_stream_t stream);
 /* out = smoothed + max(gate_raw, min_gate) * residual (spatial.py:333-335); n = element count */
 int frl_gate_blend_fwd(const void* smoothed, const void* residual, const void* gate_raw, float min_gate, void* out,
                        void* gate_out, int64_t n, int dtype, frl_stream_t stream);

@@ -547,6 +547,41 @@ def test_channel_scale_dropout2d():
         assert rel_err(xd.grad.float(), dy * sc.view(3, 1, 1, 16)) <= tol
 
 
+@pytest.mark.parametrize("B,T,HW", [(2, 5, 1024), (3, 10, 100), (1, 1, 7)])
+def test_fused_film_matches_float64(B, T, HW):
+    """csrc/film_fused.hip (bf16, 64 -> 32 -> 12): FiLMLayer's two nets + the modulation gamma * h + beta over T as one launch, and its
+    backward (d h, all eight parameter gradients contracted in-kernel) against float64 autograd of conditioning.py:82-102 /
+    representation.py:369-372 on the same bf16-rounded inputs and weights.  Pixel counts that are not multiples of the 16 / 64-pixel work
+    items; T = 1, 5, 10."""
+    from frl_hip import ops
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(B * T + HW)
+    zt = q(torch.randn(B, HW, 64, generator=g), dt)
+    h = q(torch.randn(B, T, HW, 12, generator=g), dt).requires_grad_(True)
+    shapes = [(32, 64), (32,), (12, 32), (12,), (32, 64), (32,), (12, 32), (12,)]
+    raw = [torch.randn(*s, generator=g) * (0.3 if len(s) == 2 else 0.5) for s in shapes]
+    p64 = [(q(t, dt) if t.dim() == 2 else t.double()).requires_grad_(True) for t in raw]    # weights as the matrix cores see them
+    w1g, b1g, w2g, b2g, w1b, b1b, w2b, b2b = p64
+    gamma = torch.relu(zt @ w1g.T + b1g) @ w2g.T + b2g
+    beta = torch.relu(zt @ w1b.T + b1b) @ w2b.T + b2b
+    gq, bq = q(gamma.detach(), dt), q(beta.detach(), dt)                # the kernel applies gamma / beta as it stores them (bf16)
+    z = gamma.unsqueeze(1) * h + beta.unsqueeze(1)
+    pd = [t.detach().float().to(DEV).contiguous() for t in p64]
+    ztd, hd = zt.to(dt).to(DEV), h.detach().to(dt).to(DEV)
+    assert ops.film_fused_supported(ztd, hd, 32)
+    zd, gd, bd = ops.film_fused_fwd(ztd, hd, pd)
+    assert rel_err(gd.float(), gamma.detach()) <= 8e-3 and rel_err(bd.float(), beta.detach()) <= 8e-3
+    zq = gq.unsqueeze(1) * h.detach() + bq.unsqueeze(1)
+    assert rel_err(zd.float(), zq) <= 6e-3
+    dz = q(torch.randn(B, T, HW, 12, generator=g), dt)
+    z.backward(dz)
+    dh, grads = ops.film_fused_bwd(ztd, hd, dz.to(dt).to(DEV), pd)
+    assert rel_err(dh.float(), h.grad) <= 1e-2
+    for got, ref, name in zip(grads, p64, ["w1g", "b1g", "w2g", "b2g", "w1b", "b1b", "w2b", "b2b"]):
+        assert rel_err(got, ref.grad) <= 2e-2, name
+    assert not ops.film_fused_supported(ztd.float(), hd.float(), 32) and not ops.film_fused_supported(ztd, hd, 16)
+
+
 @pytest.mark.parametrize("P,cz,use_mask", [(4096, 64, False), (5000, 12, True), (333, 12, False), (1000, 32, True), (130, 64, True)])
 def test_fused_decoder_mse(P, cz, use_mask):
     """Fused decoder + L2 loss (bf16) vs float64 autograd of the same chain, and vs the modular kernels."""

@@ -12,12 +12,13 @@
 #include <stdint.h>
 #include <stddef.h>
 
-enum { FRL_PACK_PW = 0, FRL_PACK_C3 = 1, FRL_PACK_PW_REP = 2 };
+enum { FRL_PACK_PW = 0, FRL_PACK_C3 = 1, FRL_PACK_PW_REP = 2, FRL_PACK_PW_K4 = 3 };
 
 // One contiguous run of fragments of an image, produced from one float32 weight tensor.
 //   FRL_PACK_PW: pack_weights_lds<T, NF>(dst, W, Cout, Cin, MB, so, si)        (frl_common.hpp)
 //   FRL_PACK_C3: c3_pack_kernel<T, NF>(dst, W, so, si, tap_rev, Cin, Cout)      (conv3x3.hip)
-//   FRL_PACK_PW_REP: as FRL_PACK_PW with the rows of a block replicated over the lane quarters, oc = 4 * mb + (r & 3)   (smooth_fused.hip)
+//   FRL_PACK_PW_REP: as FRL_PACK_PW with the rows of a block replicated over the lane quarters, oc = 4 * mb + (r & 3)
+//   FRL_PACK_PW_K4: as FRL_PACK_PW (NF = 1) with k-element e of lane quarter kc <-> input channel 4 kc + e for e < 4, zero beyond (film_fused.hip)
 struct FrlPackJob {
   const float* W;
   char* dst;             // absolute address once registered; offset inside the image when handed to frl_pack_cached

@@ -24,7 +24,7 @@ __device__ __forceinline__ void pk_frag_pw(const FrlPackJob& j, int i) {
     bf16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int ic = q * kc + 8 * s + e;
+      const int ic = j.kind == FRL_PACK_PW_K4 ? (e < 4 ? 4 * kc + e : j.Cin) : q * kc + 8 * s + e;
       v[e] = (oc < j.Cout && ic < j.Cin) ? (bf16)j.W[oc * j.so + ic * j.si] : (bf16)0.f;
     }
     reinterpret_cast<bf16x8*>(j.dst)[i] = v;

@@ -71,6 +71,10 @@ SIGNATURES = {
     "frl_mse_bwd": (c_int, [P, P, P, P, P, L, I, P, I, P]),
     "frl_film_modulate_fwd": (c_int, [P, P, P, P, L, I, L, I, I, P]),
     "frl_film_modulate_bwd": (c_int, [P, P, P, P, P, P, L, I, L, I, I, P]),
+    "frl_film_fused_supported": (c_int, [I, I, I, I]),
+    "frl_film_fused_workspace_bytes": (S, []),
+    "frl_film_fused_fwd": (c_int, [P] * 13 + [I, I, I, P, S, P]),
+    "frl_film_fused_bwd": (c_int, [P] * 20 + [I, I, I, P, S, P]),
     "frl_gate_blend_fwd": (c_int, [P, P, P, F, P, P, L, I, P]),
     "frl_gate_blend_bwd": (c_int, [P, P, P, P, F, P, P, L, I, P]),
     "frl_mean_time_fwd": (c_int, [P, P, L, I, L, I, P]),

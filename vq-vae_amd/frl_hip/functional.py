@@ -281,6 +281,25 @@ class FilmFn(Function):
         return ops.film_modulate_bwd(_c(dout), h, gamma)
 
 
+class FilmFusedFn(Function):
+    """FiLMLayer + modulation in one launch per direction (csrc/film_fused.hip): (h [B,T,HW..,12], z_type [B,HW..,64] stop-gradient,
+    the eight parameters of gamma_network / beta_network) -> (z = gamma * h + beta, gamma, beta)."""
+
+    @staticmethod
+    def forward(ctx, h, z_type, *params):
+        z, gamma, beta = ops.film_fused_fwd(z_type, h, params)
+        ctx.save_for_backward(h, z_type, *params)
+        ctx.mark_non_differentiable(gamma, beta)
+        return z, gamma, beta
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz, _dg, _db):
+        h, z_type, *params = ctx.saved_tensors
+        dh, grads = ops.film_fused_bwd(z_type, h, _c(dz), params)
+        return (dh if ctx.needs_input_grad[0] else None, None) + tuple(grads)
+
+
 class ChannelScaleFn(Function):
     """y[b, r, c] = x[b, r, c] * scale[b, c]  (Dropout2d mask on NHWC rows; the FiLM kernel with a single 'pixel' per sample)."""
 

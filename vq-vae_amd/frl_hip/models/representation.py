@@ -18,6 +18,7 @@ import torch.nn as nn
 
 from .. import _lib
 from .. import functional as Fh
+from .. import ops
 from .blocks import Conv2DEncoder, Conv2dParams, EdgeAwareSmoothingConv2D, FiLMLayer, TCNEncoder
 
 logger = logging.getLogger(__name__)
@@ -140,8 +141,17 @@ class RepresentationModel(nn.Module):
         self._require_gpu(x_phase)
         h = self.phase_tcn(self._rows(x_phase))
         h = self.phase_head(h)
-        gamma, beta = self.phase_film(self._rows(z_type))
-        z = Fh.FilmFn.apply(h, gamma, beta)
+        zt = self._rows(z_type)
+        film = self.phase_film
+        gn, bn = film.gamma_network, film.beta_network
+        if not zt.requires_grad and ops.film_fused_supported(zt, h, gn[0].out_channels) and all(m.bias is not None for m in (gn[0], gn[2], bn[0], bn[2])):
+            # hot configuration: both FiLM nets and the modulation as one launch per direction (csrc/film_fused.hip); the conditioning
+            # input is a stop-gradient (representation.py:350-351), which is what the fused backward assumes
+            z, gamma, beta = Fh.FilmFusedFn.apply(h, zt, gn[0].weight, gn[0].bias, gn[2].weight, gn[2].bias, bn[0].weight, bn[0].bias,
+                                                  bn[2].weight, bn[2].bias)
+        else:
+            gamma, beta = film(zt)
+            z = Fh.FilmFn.apply(h, gamma, beta)
         return (z, gamma, beta, h) if return_parts else z
 
     # ------------------------------------------------------------------ reference (channels-first) API

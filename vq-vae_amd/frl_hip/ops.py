@@ -464,6 +464,53 @@ def film_modulate_bwd(dout, h, gamma):
     return dh, dg, db
 
 
+def film_fused_supported(z_type: torch.Tensor, h: torch.Tensor, hidden: int) -> bool:
+    """True when the FiLM nets and the modulation run as one launch per direction (csrc/film_fused.hip): bf16, 64 -> 32 -> 12."""
+    return bool(z_type.is_cuda and h.dim() >= 3 and _lib.load().frl_film_fused_supported(z_type.shape[-1], hidden, h.shape[-1], _dt(h))
+                and z_type.dtype == h.dtype)
+
+
+def _film_params(params):
+    """(w1g, b1g, w2g, b2g, w1b, b1b, w2b, b2b) float32 parameters of FiLMLayer.gamma_network / beta_network"""
+    if len(params) != 8:
+        raise ValueError("film_fused: expected (w1g, b1g, w2g, b2g, w1b, b1b, w2b, b2b)")
+    return [_p(_f32(t, "film parameter")) for t in params]
+
+
+@_timed("film_fused_fwd")
+def film_fused_fwd(z_type: torch.Tensor, h: torch.Tensor, params):
+    """z_type [B,HW..,64], h [B,T,HW..,12] -> (z = gamma * h + beta, gamma [B,HW..,12], beta)."""
+    b, t, c = h.shape[0], h.shape[1], h.shape[-1]
+    hw = h.numel() // (b * t * c)
+    _chk_rows(z_type, z_type.shape[-1], "film_fused_fwd.z_type")
+    _chk_rows(h, c, "film_fused_fwd.h")
+    if z_type.numel() // z_type.shape[-1] != b * hw:
+        raise ValueError("film_fused_fwd: z_type must hold one row per (sample, pixel) of h")
+    lib = _lib.load()
+    ws = workspace(lib.frl_film_fused_workspace_bytes(), h.device)
+    z = torch.empty_like(h)
+    gamma = torch.empty(tuple(z_type.shape[:-1]) + (c,), dtype=h.dtype, device=h.device)
+    beta = torch.empty_like(gamma)
+    check(lib.frl_film_fused_fwd(_p(z_type), _p(h), *_film_params(params), _p(z), _p(gamma), _p(beta), b, t, hw, _p(ws), ws.numel(), _stream()),
+          "frl_film_fused_fwd")
+    return z, gamma, beta
+
+
+@_timed("film_fused_bwd")
+def film_fused_bwd(z_type: torch.Tensor, h: torch.Tensor, dz: torch.Tensor, params):
+    """-> (dh, [dw1g, db1g, dw2g, db2g, dw1b, db1b, dw2b, db2b])"""
+    b, t, c = h.shape[0], h.shape[1], h.shape[-1]
+    hw = h.numel() // (b * t * c)
+    _chk_like(dz, h, "film_fused_bwd.dz")
+    lib = _lib.load()
+    ws = workspace(lib.frl_film_fused_workspace_bytes(), h.device)
+    dh = torch.empty_like(h)
+    grads = [torch.empty(p.shape, dtype=torch.float32, device=h.device) for p in params]
+    check(lib.frl_film_fused_bwd(_p(z_type), _p(h), _p(dz), *_film_params(params), _p(dh), *[_p(g) for g in grads], b, t, hw, _p(ws), ws.numel(),
+                                 _stream()), "frl_film_fused_bwd")
+    return dh, grads
+
+
 @_timed("gate_blend_fwd")
 def gate_blend_fwd(smoothed, residual, gate_raw, min_gate: float):
     out = torch.empty_like(smoothed)
