@@ -224,6 +224,14 @@ int frl_tcn_hot_bwd(const void* x, const void* drop_mask, const void* dy, const 
                     const float* gn_b, const float* gate_w, const float* gate_b, void* dx, float* d_conv_w, float* d_conv_b,
                     float* d_gn_w, float* d_gn_b, float* d_gate_w, float* d_gate_b, int64_t npix, int HW, int dilation,
                     float eps, void* ws, size_t ws_bytes, frl_stream_t stream);
+/* The dense phase chain forward in ONE launch (hot configuration, three blocks with dilation 1, 2, 4: TCNEncoder.forward, tcn.py:242-290)
+ * followed by the 1x1 phase head (representation.py:169,362-366): x [B][5][HW][64] -> y1, y2, y3 (the blocks' outputs, kept for the
+ * backward) and h [B][5][HW][Ch] = head_w y3 + head_b, Ch in {4, 8, 12, 16}.  conv_w .. gate_b: arrays of three pointers (block 0, 1, 2). */
+size_t frl_tcn_chain_fwd_workspace_bytes(void);
+int frl_tcn_chain_fwd(const void* x, const float* const* conv_w, const float* const* conv_b, const float* const* gn_w,
+                      const float* const* gn_b, const float* const* gate_w, const float* const* gate_b, const float* head_w,
+                      const float* head_b, void* y1, void* y2, void* y3, void* h, int64_t npix, int HW, int Ch, float eps, void* ws,
+                      size_t ws_bytes, frl_stream_t stream);
 /* Two kernels stand behind frl_tcn_hot_bwd: tcn_hot_bwd3 (no mask, HW a multiple of 64: x of a 64-pixel tile is staged once in LDS by
  * LDS-DMA, next tile prefetched) and the 8-wave kernel that also takes a mask and ragged pixel counts.  Test hook: on != 0 routes
  * every call through the latter so that the two can be compared on the same inputs. */

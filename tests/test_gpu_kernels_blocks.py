@@ -547,6 +547,57 @@ def test_channel_scale_dropout2d():
         assert rel_err(xd.grad.float(), dy * sc.view(3, 1, 1, 16)) <= tol
 
 
+@pytest.mark.parametrize("B,HW,zp", [(2, 1024, 12), (3, 100, 8), (1, 37, 16)])
+def test_phase_chain_forward_in_one_launch_equals_the_block_by_block_path(B, HW, zp):
+    """tcn_chain_fwd_kernel: the three hot GatedResidualBlocks (dilation 1, 2, 4) + the 1x1 phase head in one launch.  The blocks hand
+    their outputs on in registers, rounded to bf16 exactly where the stand-alone kernels round on their store, so y1, y2, y3 must EQUAL
+    the block-by-block launches bit for bit; the head agrees with the 1x1 convolution kernel to bf16 rounding; the backward (head kernels
+    + three fused block backward kernels on the saved inputs) yields the gradients of the modular autograd chain."""
+    from frl_hip import ops
+    from frl_hip import functional as Fh
+    from frl_hip.models.blocks import Conv2dParams, TCNEncoder
+    torch.manual_seed(HW + zp)
+    tcn = TCNEncoder(64, [64, 64, 64], 3, [1, 2, 4], 0.0, 8).to(DEV)
+    head = Conv2dParams(64, zp, 1).to(DEV)
+    with torch.no_grad():
+        for l in tcn.layers:
+            l.norm.weight.uniform_(0.5, 1.5)
+            l.norm.bias.uniform_(-0.3, 0.3)
+    x = torch.randn(B, 5, HW, 64, generator=torch.Generator().manual_seed(3)).to(torch.bfloat16).to(DEV)
+    blocks = [(l.conv.weight, l.conv.bias, l.norm.weight, l.norm.bias, l.gate.weight, l.gate.bias, l.dilation, 8, False) for l in tcn.layers]
+    assert ops.tcn_chain_supported(x, blocks, head.weight)
+    y1, y2, y3, h = ops.tcn_chain_fwd(x, blocks, head.weight, head.bias)
+    ref, outs = x, []
+    for blk in blocks:
+        ref = ops.tcn_block_fwd(ref, *blk[:6], None, None, blk[6], 8)
+        outs.append(ref)
+    for got, want in zip((y1, y2, y3), outs):
+        assert torch.equal(got, want)
+    href = ops.conv1x1_fwd(outs[2], head.weight.reshape(zp, 64), head.bias, ops.ACT_NONE)
+    assert (h.float() - href.float()).abs().max().item() <= 8e-3 * href.float().abs().max().item()
+    # autograd: chain node vs modular modules
+    dh = torch.randn(B, 5, HW, zp, generator=torch.Generator().manual_seed(4)).to(torch.bfloat16).to(DEV)
+    params = list(tcn.parameters()) + list(head.parameters())
+    res = []
+    for chained in (True, False):
+        for p_ in params:
+            p_.grad = None
+        xin = x.clone().requires_grad_(True)
+        if chained:
+            flat = [t for blk in blocks for t in blk[:6]]
+            out = Fh.TcnChainHeadFn.apply(xin, *flat, head.weight, head.bias, 8, 1e-5)
+        else:
+            out = head(tcn(xin))
+        out.backward(dh)
+        res.append((out.detach(), xin.grad.detach(), [p_.grad.detach().clone() for p_ in params]))
+    assert (res[0][0].float() - res[1][0].float()).abs().max().item() <= 8e-3 * res[1][0].float().abs().max().item()
+    assert torch.equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.equal(a, b)
+    assert not ops.tcn_chain_supported(x.float(), blocks, head.weight)
+    assert not ops.tcn_chain_supported(x, blocks[:2], head.weight)
+
+
 @pytest.mark.parametrize("B,T,HW", [(2, 5, 1024), (3, 10, 100), (1, 1, 7)])
 def test_fused_film_matches_float64(B, T, HW):
     """csrc/film_fused.hip (bf16, 64 -> 32 -> 12): FiLMLayer's two nets + the modulation gamma * h + beta over T as one launch, and its

@@ -185,6 +185,151 @@ __global__ __launch_bounds__(256, 2) void tcn_hot_fwd_kernel(const bf16* __restr
 }
 
 // =============================================================================================================
+// forward, the whole dense phase chain in ONE launch: three GatedResidualBlocks (dilation 1, 2, 4; tcn.py:242-290) followed by the
+// 1x1 phase head (representation.py:169,362-366).  A wave carries its 16 pixel series through the three blocks in registers: the
+// block's output IS the next block's lane-quarter input image (rounded to bf16 exactly where the stand-alone kernels round it on their
+// store), so the tile is read once; y1, y2 (the inputs the block backward passes recompute from), y3 (the head's weight-gradient operand)
+// and the 12-channel head output are written once each.  Against three block launches + the head's 1x1 convolution this drops the
+// re-reads of y1, y2, y3 (3 x 168 MB at cfg2) and three launches.  8 waves per workgroup (two per SIMD), all three weight images
+// resident in LDS (3 x 32 KB), the next tile's rows prefetched into registers behind the current tile's three blocks.
+// =============================================================================================================
+template <int DIL>
+__device__ __forceinline__ void th_block_regs(Tile2 (&x)[TH_T], const frag8* __restrict__ wl_conv, const frag8* __restrict__ wl_gate,
+                                              const float* __restrict__ tab, int lane, int kc, float eps) {
+  const f32x4* tcb = reinterpret_cast<const f32x4*>(tab + 16 * kc);
+  const float* tgw0 = tab + 64 + 16 * kc;
+  const float* tgb0 = tab + 128 + 16 * kc;
+  const float* tnbg0 = tab + 192 + 16 * kc;
+  f32x4 acc[TH_T][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const f32x4 cb = tcb[m];
+#pragma unroll
+    for (int t = 0; t < TH_T; ++t) acc[t][m] = cb;
+  }
+  th_conv<DIL>(acc, x, wl_conv, lane);
+  float mean[2], rstd[2];
+  th_stats(acc, eps, mean, rstd);
+  const float nm[2] = {-mean[0] * rstd[0], -mean[1] * rstd[1]};
+#pragma unroll
+  for (int t = 0; t < TH_T; ++t) {
+    __builtin_amdgcn_sched_barrier(0);
+    int zt = 0;
+    asm volatile("" : "+s"(zt));                                    // per-channel constants re-read from LDS per time step (48 registers less)
+    const float* tgw = tgw0 + zt;
+    const float* tgb = tgb0 + zt;
+    const float* tnbg = tnbg0 + zt;
+    float n[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) n[j] = fmaf(fmaf(acc[t][j >> 2][j & 3], rstd[j >> 3], nm[j >> 3]), tgw[j], tgb[j]);
+    const Tile2 nt = th_pack(n);
+    f32x4 gacc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      gacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 2; ++s) gacc[m] = mfma16(wl_gate[(m * 2 + s) * 64 + lane], nt.f[s], gacc[m]);
+    }
+    float y[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float g = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(gacc[j >> 2][j & 3], -1.44269504088896f, tnbg[j])));
+      const float o = fmaxf(n[j], 0.f);
+      const float res = th_elem(x[t], j);
+      y[j] = fmaf(g, o - res, res);
+    }
+    x[t] = th_pack(y);                                              // (x[t] was last needed as this step's residual)
+  }
+}
+
+struct ThChainArgs {
+  const frag8* pk[3];                                              // packed images of the three blocks (layout of tcn_hot_pack_kernel)
+  const float* bc[3]; const float* gw[3]; const float* gb[3]; const float* bg[3];
+  const frag8* pkh;                                                // head: [2 k-steps][64] fragments (one 16-row block)
+  const float* bh;                                                 // head bias [Ch]
+  bf16* y[3];
+  bf16* h;
+};
+
+#define THC_IMG (32 * 64)                                          // fragments of one block's forward image (conv taps + gate)
+__global__ __launch_bounds__(512, 2) void tcn_chain_fwd_kernel(const bf16* __restrict__ X, ThChainArgs a, int64_t npix, int HW, int Ch, float eps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  frag8* wl = reinterpret_cast<frag8*>(smem);                      // [3][THC_IMG]
+  frag8* wlh = wl + 3 * THC_IMG;                                   // [2][64]
+  float* tab = reinterpret_cast<float*>(wlh + 2 * 64);             // [3][256]: conv bias | gamma | beta | -log2e * gate bias;  then head bias [16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, kc = lane >> 4;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) copy_frags_lds<bf16>(wl + b * THC_IMG, a.pk[b], THC_IMG, tid, 512);
+  copy_frags_lds<bf16>(wlh, a.pkh, 2 * 64, tid, 512);
+  for (int i = tid; i < 3 * 256 + 16; i += 512) {
+    float v;
+    if (i < 768) {
+      const int b = i >> 8, w = (i >> 6) & 3, c = i & 63;
+      v = w == 0 ? a.bc[b][c] : w == 1 ? a.gw[b][c] : w == 2 ? a.gb[b][c] : -1.44269504088896f * a.bg[b][c];
+    } else {
+      v = (i - 768) < Ch ? a.bh[i - 768] : 0.f;
+    }
+    tab[i] = v;
+  }
+  __syncthreads();
+  const int64_t ntile = (npix + 15) >> 4;
+  const int64_t tstep = (int64_t)gridDim.x * 8;
+  auto rows = [&](int64_t tile, bool& valid) -> int64_t {          // element offset of (t = 0, this lane's pixel, its channel quarter)
+    int64_t pidx = tile * 16 + px;
+    valid = pidx < npix;
+    if (!valid) pidx = npix - 1;
+    const int64_t b = pidx / HW, hw = pidx % HW;
+    return (b * TH_T * HW + hw) * 64 + 16 * kc;
+  };
+  Tile2 x[TH_T];
+  {
+    bool v;
+    const int64_t t0 = (int64_t)blockIdx.x * 8 + wave;
+    const int64_t r0 = rows(t0 < ntile ? t0 : 0, v);
+#pragma unroll
+    for (int t = 0; t < TH_T; ++t) x[t] = th_load(X + r0 + (int64_t)t * HW * 64);
+  }
+  for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntile; tile += tstep) {
+    bool valid, vn;
+    const int64_t r0 = rows(tile, valid);
+    int lw = lane, z0 = 0;
+    asm volatile("" : "+v"(lw), "+s"(z0));                        // opaque per tile: neither the weight fragments nor the 3 x 48 per-channel
+    const float* tb_ = tab + z0;                                  // constants are hoisted out of the tile loop into registers
+    th_block_regs<1>(x, wl, wl + 24 * 64, tb_, lw, kc, eps);
+    if (valid) {
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t) th_store(a.y[0] + r0 + (int64_t)t * HW * 64, x[t]);
+    }
+    __builtin_amdgcn_sched_barrier(0);                             // (one block at a time: interleaved, the three bodies do not fit the register file)
+    th_block_regs<2>(x, wl + THC_IMG, wl + THC_IMG + 24 * 64, tb_ + 256, lw, kc, eps);
+    if (valid) {
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t) th_store(a.y[1] + r0 + (int64_t)t * HW * 64, x[t]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    th_block_regs<4>(x, wl + 2 * THC_IMG, wl + 2 * THC_IMG + 24 * 64, tb_ + 512, lw, kc, eps);
+    __builtin_amdgcn_sched_barrier(0);
+    // phase head: h[t] = W_h y3[t] + b_h, Ch <= 16 output channels: lane quarter kc holds channels 4 kc .. 4 kc + 3
+    const f32x4 hb4 = *reinterpret_cast<const f32x4*>(tb_ + 768 + 4 * kc);
+    const int64_t hrow = (r0 - 16 * kc) / 64 * Ch + 4 * kc;
+#pragma unroll
+    for (int t = 0; t < TH_T; ++t) {
+      if (valid) th_store(a.y[2] + r0 + (int64_t)t * HW * 64, x[t]);
+      f32x4 ha = mfma16(wlh[lw], x[t].f[0], hb4);
+      ha = mfma16(wlh[64 + lw], x[t].f[1], ha);
+      if (valid && 4 * kc < Ch)
+        *reinterpret_cast<bf16x4*>(a.h + hrow + (int64_t)t * HW * Ch) = bf16x4{(bf16)ha[0], (bf16)ha[1], (bf16)ha[2], (bf16)ha[3]};
+    }
+    {                                                               // next tile's rows
+      const int64_t rn = rows(tile + tstep < ntile ? tile + tstep : tile, vn);
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t) x[t] = th_load(X + rn + (int64_t)t * HW * 64);
+    }
+  }
+}
+
+// =============================================================================================================
 // backward
 // =============================================================================================================
 // k-strided MFMA fragment (8 consecutive pixels of one channel) from a [pixel][TH_PITCH] LDS tile
@@ -682,6 +827,39 @@ int frl_tcn_hot_fwd(const void* x, const void* drop_mask, const float* conv_w, c
   else return frl_fail(-2, "tcn_hot_fwd: dilation must be 1, 2 or 4");
   if (rc) return rc;
   return frl_check_launch("tcn_hot_fwd");
+}
+
+// The dense phase chain forward in one launch: x [B][5][HW][64] -> y1, y2, y3 (outputs of the blocks with dilation 1, 2, 4; same shape) and
+// h [B][5][HW][Ch] = head_w y3 + head_b (Ch <= 16, a multiple of 4).  Block parameters as in frl_tcn_hot_fwd, one set per block.
+size_t frl_tcn_chain_fwd_workspace_bytes(void) { return 3 * TH_PACK_BYTES + 4096; }
+int frl_tcn_chain_fwd(const void* x, const float* const* conv_w, const float* const* conv_b, const float* const* gn_w, const float* const* gn_b,
+                      const float* const* gate_w, const float* const* gate_b, const float* head_w, const float* head_b, void* y1, void* y2, void* y3,
+                      void* h, int64_t npix, int HW, int Ch, float eps, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (npix <= 0 || HW <= 0) return frl_fail(-2, "tcn_chain_fwd: empty input");
+  if (Ch < 4 || Ch > 16 || (Ch & 3)) return frl_fail(-2, "tcn_chain_fwd: head width must be 4, 8, 12 or 16");
+  if (ws == nullptr || ws_bytes < frl_tcn_chain_fwd_workspace_bytes()) return frl_fail(-4, "tcn_chain_fwd: workspace too small");
+  ThChainArgs a;
+  char* w = (char*)ws;
+  for (int b = 0; b < 3; ++b) {
+    a.pk[b] = th_packed(conv_w[b], gate_w[b], reinterpret_cast<frag8*>(w + b * TH_PACK_BYTES), stream);
+    a.bc[b] = conv_b[b]; a.gw[b] = gn_w[b]; a.gb[b] = gn_b[b]; a.bg[b] = gate_b[b];
+  }
+  {
+    FrlPackJob job = frl_pack_job_pw(head_w, 0, FRL_BF16, 2, Ch, 64, 1, 64, 1);
+    bool hit = false;
+    frag8* pk = reinterpret_cast<frag8*>(w + 3 * TH_PACK_BYTES);
+    if (void* img = frl_pack_cached(&job, 1, (size_t)2 * 64 * sizeof(frag8), &hit)) pk = (frag8*)img;
+    if (!hit) FRL_LAUNCH((pack_weights_kernel<bf16, 2>), dim3(1), dim3(128), 0, stream, pk, head_w, Ch, 64, 1, (int64_t)64, (int64_t)1);
+    a.pkh = pk;
+  }
+  a.bh = head_b;
+  a.y[0] = (bf16*)y1; a.y[1] = (bf16*)y2; a.y[2] = (bf16*)y3; a.h = (bf16*)h;
+  int64_t g = ((npix + 15) / 16 + 7) / 8;
+  if (g > 256) g = 256;
+  const size_t lds = (size_t)(3 * THC_IMG + 2 * 64) * sizeof(frag8) + (3 * 256 + 16) * sizeof(float);
+  FRL_HIP(hipFuncSetAttribute((const void*)tcn_chain_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  FRL_LAUNCH(tcn_chain_fwd_kernel, dim3((unsigned)g), dim3(512), lds, stream, (const bf16*)x, a, npix, HW, Ch, eps);
+  return frl_check_launch("tcn_chain_fwd");
 }
 
 // one launch: dx [B][5][HW][64] bf16 and all parameter gradients (float32, reference layouts); drop_mask as in the forward

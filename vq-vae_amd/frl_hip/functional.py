@@ -266,6 +266,38 @@ class TcnBlockFn(Function):
                 g["gate_b"], dpw, g.get("proj_b"), None, None, None, None)
 
 
+class TcnChainHeadFn(Function):
+    """Three hot GatedResidualBlocks (dilation 1, 2, 4) + the 1x1 phase head: ONE forward launch (ops.tcn_chain_fwd); the backward runs the
+    head's two kernels and the three fused block backward kernels on the saved block inputs x, y1, y2 (and y3 for the head's weights).
+    args: x, 3 x (conv_w, conv_b, gn_w, gn_b, gate_w, gate_b), head_w, head_b, groups, eps."""
+
+    @staticmethod
+    def forward(ctx, x, *args):
+        params, (head_w, head_b, groups, eps) = args[:18], args[18:]
+        blocks = [tuple(params[6 * i:6 * i + 6]) + (d, groups, False) for i, d in enumerate((1, 2, 4))]
+        y1, y2, y3, h = ops.tcn_chain_fwd(x, blocks, head_w, head_b, eps)
+        ctx.cfg = (groups, eps)
+        ctx.save_for_backward(x, y1, y2, y3, head_w, *params)
+        return h
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dh):
+        x, y1, y2, y3, head_w, *params = ctx.saved_tensors
+        groups, eps = ctx.cfg
+        dh = _c(dh)
+        w2 = head_w.reshape(head_w.shape[0], head_w.shape[1])
+        dy = ops.conv1x1_bwd_data(dh, w2, None, ACT_NONE)
+        dw_h, db_h = ops.conv1x1_bwd_weight(dh, y3, None, ACT_NONE, want_bias=True)
+        grads = [None] * 18
+        for i, (xin, dil) in reversed(list(enumerate(zip((x, y1, y2), (1, 2, 4))))):
+            cw, cb, gw, gb, tw, tb = params[6 * i:6 * i + 6]
+            g = ops.tcn_block_bwd(xin, dy, cw, cb, gw, gb, tw, tb, None, None, dil, groups, eps)
+            grads[6 * i:6 * i + 6] = [g["conv_w"], g["conv_b"], g["gn_w"], g["gn_b"], g["gate_w"], g["gate_b"]]
+            dy = g["dx"]
+        return (dy if ctx.needs_input_grad[0] else None,) + tuple(grads) + (dw_h.reshape(head_w.shape), db_h, None, None)
+
+
 class FilmFn(Function):
     """z[b,t,p,c] = gamma[b,p,c] * h[b,t,p,c] + beta[b,p,c]."""
 

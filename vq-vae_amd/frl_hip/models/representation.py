@@ -136,11 +136,24 @@ class RepresentationModel(nn.Module):
         h = self.encoder(self._rows(x))
         return self.spatial_conv(h, return_gate=return_gate)
 
+    def _phase_chain(self, x: torch.Tensor) -> torch.Tensor:
+        """phase_tcn -> phase_head on [B,T,HW..,C] rows.  Hot configuration (bf16, three 64-channel blocks with dilation 1, 2, 4, T = 5,
+        no active Dropout1d, a head of <= 16 channels): one forward launch for the whole chain (Fh.TcnChainHeadFn)."""
+        tcn, head = self.phase_tcn, self.phase_head
+        layers = list(tcn.layers)
+        drop = any(self.training and l.dropout.p > 0.0 for l in layers)
+        if len(layers) == 3 and not drop and head.k == 1 and head.bias is not None:
+            blocks = [(l.conv.weight, l.conv.bias, l.norm.weight, l.norm.bias, l.gate.weight, l.gate.bias, l.dilation, l.norm.num_groups,
+                       l.needs_projection) for l in layers]
+            if ops.tcn_chain_supported(x, blocks, head.weight):
+                flat = [t for blk in blocks for t in blk[:6]]
+                return Fh.TcnChainHeadFn.apply(x, *flat, head.weight, head.bias, layers[0].norm.num_groups, layers[0].norm.eps)
+        return head(tcn(x))
+
     def forward_phase_nhwc(self, x_phase: torch.Tensor, z_type: torch.Tensor, return_parts: bool = False):
         """x_phase [B,T,H,W,C_phase], z_type [B,H,W,d] (caller stop-grads) -> z_phase [B,T,H,W,zp]."""
         self._require_gpu(x_phase)
-        h = self.phase_tcn(self._rows(x_phase))
-        h = self.phase_head(h)
+        h = self._phase_chain(self._rows(x_phase))
         zt = self._rows(z_type)
         film = self.phase_film
         gn, bn = film.gamma_network, film.beta_network

@@ -841,6 +841,39 @@ def tcn_block_fwd(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b,
     return y
 
 
+def tcn_chain_supported(x: torch.Tensor, blocks, head_w: torch.Tensor) -> bool:
+    """True when three blocks (dilation 1, 2, 4; hot configuration each) and the 1x1 head run as ONE forward launch (tcn_chain_fwd_kernel).
+    blocks: three tuples (conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, dilation, groups, has_projection)."""
+    if len(blocks) != 3 or x.dim() < 3 or not x.is_cuda:
+        return False
+    lib = _lib.load()
+    t, c = x.shape[1], x.shape[-1]
+    for blk, dil in zip(blocks, (1, 2, 4)):
+        if blk[6] != dil or not lib.frl_tcn_hot_supported(t, c, blk[0].shape[0], blk[7], dil, int(blk[8]), _dt(x)):
+            return False
+    ch = head_w.shape[0]
+    return head_w.shape[1] == 64 and ch in (4, 8, 12, 16)
+
+
+@_timed("tcn_chain_fwd")
+def tcn_chain_fwd(x, blocks, head_w, head_b, eps: float = 1e-5):
+    """x [B,5,HW..,64] -> (y1, y2, y3 [same shape], h [B,5,HW..,Ch])."""
+    b, t, c = x.shape[0], x.shape[1], x.shape[-1]
+    hw = x.numel() // (b * t * c)
+    _chk_rows(x, c, "tcn_chain_fwd.x")
+    ch = head_w.shape[0]
+    lib = _lib.load()
+    ws = workspace(lib.frl_tcn_chain_fwd_workspace_bytes(), x.device)
+    ys = [torch.empty_like(x) for _ in range(3)]
+    h = torch.empty(x.shape[:-1] + (ch,), dtype=x.dtype, device=x.device)
+    arr = ctypes.c_void_p * 3
+    cols = [arr(*[_f32(blk[i] if i != 4 else blk[i].reshape(c, c), "tcn parameter").data_ptr() for blk in blocks]) for i in range(6)]
+    check(lib.frl_tcn_chain_fwd(_p(x), *[ctypes.cast(a, ctypes.c_void_p) for a in cols], _p(_f32(head_w.reshape(ch, c), "head_w")), _p(_f32(head_b, "head_b")),
+                                _p(ys[0]), _p(ys[1]), _p(ys[2]), _p(h), b * hw, hw, ch, float(eps), _p(ws), ws.numel(), _stream()),
+          "frl_tcn_chain_fwd")
+    return ys[0], ys[1], ys[2], h
+
+
 @_timed("tcn_block_bwd")
 def tcn_block_bwd(x, dy, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, dilation: int, groups: int,
                   eps: float = 1e-5, allow_fused: bool = True, allow_hot: bool = True, drop_mask=None):
