@@ -220,6 +220,8 @@ size_t frl_tcn_hot_bwd_workspace_bytes(int64_t npix);
 int frl_tcn_hot_fwd(const void* x, const void* drop_mask, const float* conv_w, const float* conv_b, const float* gn_w, const float* gn_b,
                     const float* gate_w, const float* gate_b, void* y, int64_t npix, int HW, int dilation, float eps, void* ws,
                     size_t ws_bytes, frl_stream_t stream);
+/* 1: frl_tcn_hot_bwd takes dx = NULL for this shape (block input without gradient: no conv^T GEMM, no dx store; drop_mask must be NULL) */
+int frl_tcn_hot_bwd_nodx_supported(int64_t npix, int HW);
 int frl_tcn_hot_bwd(const void* x, const void* drop_mask, const void* dy, const float* conv_w, const float* conv_b, const float* gn_w,
                     const float* gn_b, const float* gate_w, const float* gate_b, void* dx, float* d_conv_w, float* d_conv_b,
                     float* d_gn_w, float* d_gn_b, float* d_gate_w, float* d_gate_b, int64_t npix, int HW, int dilation,

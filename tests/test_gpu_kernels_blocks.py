@@ -594,6 +594,17 @@ def test_phase_chain_forward_in_one_launch_equals_the_block_by_block_path(B, HW,
     assert torch.equal(res[0][1], res[1][1])
     for a, b in zip(res[0][2], res[1][2]):
         assert torch.equal(a, b)
+    # the chain's input is data in the model (the tile itself): block 1 then runs the backward without its conv^T GEMM / dx store;
+    # parameter gradients are the same bits
+    if HW % 64 == 0:
+        for p_ in params:
+            p_.grad = None
+        flat = [t for blk in blocks for t in blk[:6]]
+        Fh.TcnChainHeadFn.apply(x, *flat, head.weight, head.bias, 8, 1e-5).backward(dh)
+        for p_, b in zip(params, res[0][2]):
+            assert torch.equal(p_.grad, b)
+        g = ops.tcn_block_bwd(x, y1, *blocks[0][:6], None, None, 1, 8, want_dx=False)
+        assert g["dx"] is None
     assert not ops.tcn_chain_supported(x.float(), blocks, head.weight)
     assert not ops.tcn_chain_supported(x, blocks[:2], head.weight)
 

@@ -48,27 +48,29 @@ __device__ __forceinline__ void th_conv(f32x4 (&acc)[TH_T][4], const Tile2 (&x)[
       }
 }
 
-// exact two-pass GroupNorm statistics of the lane's two 8-channel groups over (8 ch x 5 t); acc already holds conv + bias
+// exact two-pass GroupNorm statistics of the lane's two 8-channel groups over (8 ch x 5 t); acc already holds conv + bias.
+// Four independent partial sums per reduction (one per accumulator register): the 40-term chains become 10-term chains, which matters
+// at two waves per SIMD where nothing else hides the dependent-add latency.
 __device__ __forceinline__ void th_stats(const f32x4 (&acc)[TH_T][4], float eps, float (&mean)[2], float (&rstd)[2]) {
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
-    float s = 0.f;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < TH_T; ++t)
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s += acc[t][2 * g + m][r];
-    const float mu = s * (1.f / 40.f);
-    float q = 0.f;
+        for (int r = 0; r < 4; ++r) s[r] += acc[t][2 * g + m][r];
+    const float mu = ((s[0] + s[1]) + (s[2] + s[3])) * (1.f / 40.f);
+    f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < TH_T; ++t)
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float d = acc[t][2 * g + m][r] - mu; q = fmaf(d, d, q); }
+        for (int r = 0; r < 4; ++r) { const float d = acc[t][2 * g + m][r] - mu; q[r] = fmaf(d, d, q[r]); }
     mean[g] = mu;
-    rstd[g] = 1.f / sqrtf(q * (1.f / 40.f) + eps);
+    rstd[g] = 1.f / sqrtf(((q[0] + q[1]) + (q[2] + q[3])) * (1.f / 40.f) + eps);
   }
 }
 
@@ -809,6 +811,9 @@ int frl_tcn_hot_supported(int T, int Cin, int Cout, int G, int dilation, int has
   return dtype == FRL_BF16 && Cin == 64 && Cout == 64 && T == TH_T && G == 8 && !has_proj && (dilation == 1 || dilation == 2 || dilation == 4);
 }
 
+// 1 when frl_tcn_hot_bwd accepts dx = NULL for this shape (the input needs no gradient: conv^T GEMM and dx store are skipped)
+int frl_tcn_hot_bwd_nodx_supported(int64_t npix, int HW) { return (th_bwd3_supported(npix, HW) && !g_th_force_bwd2) ? 1 : 0; }
+
 size_t frl_tcn_hot_fwd_workspace_bytes(void) { return TH_PACK_BYTES; }
 size_t frl_tcn_hot_bwd_workspace_bytes(int64_t npix) { return (size_t)th_bwd_grid(npix) * TH_SLAB * sizeof(float) + 256 + TH_PACK_BYTES; }
 
@@ -875,6 +880,8 @@ int frl_tcn_hot_bwd(const void* x, const void* drop_mask, const void* dy, const 
   const frag8* pk = th_packed(conv_w, gate_w,
                               reinterpret_cast<frag8*>(reinterpret_cast<char*>(ws) + (((size_t)grid * TH_SLAB * sizeof(float) + 255) / 256) * 256), stream);
   int rc = -2;
+  if (dx == nullptr && !(drop_mask == nullptr && th_bwd3_supported(npix, HW) && !g_th_force_bwd2))
+    return frl_fail(-2, "tcn_hot_bwd: dx may be NULL (input without gradient) only on the tcn_hot_bwd3 route (no mask, HW % 64 == 0)");
   if (drop_mask == nullptr && th_bwd3_supported(npix, HW) && !g_th_force_bwd2)      // the measured configuration: tcn_hot_bwd3.hip
     rc = th_bwd3_launch(dilation, x, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
   else if (dilation == 1) rc = th_launch_bwd<1>(x, drop_mask, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);

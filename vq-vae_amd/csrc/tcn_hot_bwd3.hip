@@ -100,7 +100,9 @@ __device__ unsigned long long* b3_dbg;
 #define B3_ST(i) do { } while (0)
 #endif
 
-template <int DIL>
+// WANT_DX = false: the block's input is data (the first block of the phase path reads the tile itself): the conv^T GEMM, the residual
+// gradient and the dx store are compiled out.
+template <int DIL, bool WANT_DX>
 __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __restrict__ X, const bf16* __restrict__ DY, const frag8* __restrict__ Wpk,
                                                               const float* __restrict__ bc, const float* __restrict__ gn_w,
                                                               const float* __restrict__ gn_b, const float* __restrict__ bg, bf16* __restrict__ DX,
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __rest
           dnr[e] = n > 0.f ? dyg : 0.f;
         }
         b3_st(smem, aoff + t * B3_TT + oo, th_pack8(dgp));
-        dres[t] = th_pack8(drv);
+        if constexpr (WANT_DX) dres[t] = th_pack8(drv);
         dn0[t] = th_pack8(dnr);
       }
     }
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __rest
     B3_BARRIER();                                                  // D (LDS only: the DMA and the dy loads stay in flight)
     B3_ST(9);
     // ---------------- dx[t'] = sum_k W_k^T dconv[t' - (k-1) d] + dres[t'] (this wave's 8 channels per lane) ----------------
-    {
+    if constexpr (WANT_DX) {
       B3_ADDR();
       f32x4 dxa[TH_T][2];
 #pragma unroll
@@ -501,9 +503,15 @@ bool th_bwd3_supported(int64_t npix, int HW) { return HW > 0 && HW % 64 == 0 && 
 template <int DIL>
 static void b3_launch(const void* x, const void* dy, const frag8* pk, const float* bc, const float* gw, const float* gb, const float* bg, void* dx,
                       float* slab, unsigned grid, int ntile, int HW, float eps, hipStream_t st) {
-  auto kern = tcn_hot_bwd3_kernel<DIL>;
-  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_LDS);
-  FRL_LAUNCH_AS("tcn_hot_bwd3_kernel", kern, dim3(grid), dim3(512), B3_LDS, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx, slab, ntile, HW, eps);
+  if (dx != nullptr) {
+    auto kern = tcn_hot_bwd3_kernel<DIL, true>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_LDS);
+    FRL_LAUNCH_AS("tcn_hot_bwd3_kernel", kern, dim3(grid), dim3(512), B3_LDS, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx, slab, ntile, HW, eps);
+  } else {
+    auto kern = tcn_hot_bwd3_kernel<DIL, false>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_LDS);
+    FRL_LAUNCH_AS("tcn_hot_bwd3_nodx_kernel", kern, dim3(grid), dim3(512), B3_LDS, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)nullptr, slab, ntile, HW, eps);
+  }
 }
 
 int th_bwd3_launch(int dilation, const void* x, const void* dy, const frag8* pk, const float* bc, const float* gw, const float* gb, const float* bg,

@@ -260,7 +260,7 @@ class TcnBlockFn(Function):
         dilation, groups, eps = ctx.cfg
         pw = None if proj_w is None else proj_w.reshape(proj_w.shape[0], proj_w.shape[1])
         g = ops.tcn_block_bwd(x, _c(dy), conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, pw, proj_b, dilation, groups, eps,
-                              drop_mask=ctx.drop_mask)
+                              drop_mask=ctx.drop_mask, want_dx=ctx.needs_input_grad[0])
         dpw = g["proj_w"].reshape(proj_w.shape) if proj_w is not None else None
         return (g["dx"] if ctx.needs_input_grad[0] else None, g["conv_w"], g["conv_b"], g["gn_w"], g["gn_b"], g["gate_w"],
                 g["gate_b"], dpw, g.get("proj_b"), None, None, None, None)
@@ -292,7 +292,7 @@ class TcnChainHeadFn(Function):
         grads = [None] * 18
         for i, (xin, dil) in reversed(list(enumerate(zip((x, y1, y2), (1, 2, 4))))):
             cw, cb, gw, gb, tw, tb = params[6 * i:6 * i + 6]
-            g = ops.tcn_block_bwd(xin, dy, cw, cb, gw, gb, tw, tb, None, None, dil, groups, eps)
+            g = ops.tcn_block_bwd(xin, dy, cw, cb, gw, gb, tw, tb, None, None, dil, groups, eps, want_dx=(i > 0 or ctx.needs_input_grad[0]))
             grads[6 * i:6 * i + 6] = [g["conv_w"], g["conv_b"], g["gn_w"], g["gn_b"], g["gate_w"], g["gate_b"]]
             dy = g["dx"]
         return (dy if ctx.needs_input_grad[0] else None,) + tuple(grads) + (dw_h.reshape(head_w.shape), db_h, None, None)

@@ -466,7 +466,7 @@ def film_modulate_bwd(dout, h, gamma):
 
 def film_fused_supported(z_type: torch.Tensor, h: torch.Tensor, hidden: int) -> bool:
     """True when the FiLM nets and the modulation run as one launch per direction (csrc/film_fused.hip): bf16, 64 -> 32 -> 12."""
-    return bool(z_type.is_cuda and h.dim() >= 3 and _lib.load().frl_film_fused_supported(z_type.shape[-1], hidden, h.shape[-1], _dt(h))
+    return bool(z_type.is_cuda and h.dim() >= 3 and fusion_enabled("film") and _lib.load().frl_film_fused_supported(z_type.shape[-1], hidden, h.shape[-1], _dt(h))
                 and z_type.dtype == h.dtype)
 
 
@@ -752,10 +752,16 @@ def edge_smooth_bwd(d_smoothed, x, a_soft, b_soft, rank: int, coarse_dilation: i
     return dx, da, db
 
 
+def fusion_enabled(name: str) -> bool:
+    """A/B switch for measurements: FRL_HIP_DISABLE=chain,film,heads routes the named fusions through their modular kernels."""
+    import os
+    return name not in os.environ.get("FRL_HIP_DISABLE", "").split(",")
+
+
 def smooth_heads_supported(x: torch.Tensor, hidden: int, rank: int, wa, ba, wb, bb) -> bool:
     """True when the two mixing heads, their softmaxes and the directional bank run as ONE kernel per direction (csrc/smooth_fused.hip):
     bf16 rows of 64 channels, 64 hidden features, rank 4, both heads with a bias."""
-    if ba is None or bb is None or x.dim() != 4 or not x.is_cuda:
+    if ba is None or bb is None or x.dim() != 4 or not x.is_cuda or not fusion_enabled("heads"):
         return False
     if tuple(wa.shape[:2]) != (8 * rank, hidden) or tuple(wb.shape[:2]) != (x.shape[-1] * rank, hidden):
         return False
@@ -844,7 +850,7 @@ def tcn_block_fwd(x, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b,
 def tcn_chain_supported(x: torch.Tensor, blocks, head_w: torch.Tensor) -> bool:
     """True when three blocks (dilation 1, 2, 4; hot configuration each) and the 1x1 head run as ONE forward launch (tcn_chain_fwd_kernel).
     blocks: three tuples (conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, dilation, groups, has_projection)."""
-    if len(blocks) != 3 or x.dim() < 3 or not x.is_cuda:
+    if len(blocks) != 3 or x.dim() < 3 or not x.is_cuda or not fusion_enabled("chain"):
         return False
     lib = _lib.load()
     t, c = x.shape[1], x.shape[-1]
@@ -876,8 +882,9 @@ def tcn_chain_fwd(x, blocks, head_w, head_b, eps: float = 1e-5):
 
 @_timed("tcn_block_bwd")
 def tcn_block_bwd(x, dy, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, dilation: int, groups: int,
-                  eps: float = 1e-5, allow_fused: bool = True, allow_hot: bool = True, drop_mask=None):
-    """Returns dict(dx, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b[, proj_w, proj_b]) gradients."""
+                  eps: float = 1e-5, allow_fused: bool = True, allow_hot: bool = True, drop_mask=None, want_dx: bool = True):
+    """Returns dict(dx, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b[, proj_w, proj_b]) gradients.  want_dx=False (the block's input
+    needs no gradient): dx is None where the kernel can skip it (hot configuration without mask), otherwise computed as usual."""
     b, t, cin = x.shape[0], x.shape[1], x.shape[-1]
     cout = conv_w.shape[0]
     hw = x.numel() // (b * t * cin)
@@ -887,7 +894,8 @@ def tcn_block_bwd(x, dy, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, pro
     hot = bool(allow_fused and allow_hot and lib.frl_tcn_hot_supported(t, cin, cout, groups, dilation, int(proj_w is not None), _dt(x)))
     _check_drop_mask(drop_mask, x, hot)
     if hot:
-        dx = torch.empty_like(x)
+        skip_dx = (not want_dx) and drop_mask is None and bool(lib.frl_tcn_hot_bwd_nodx_supported(npix, hw))
+        dx = None if skip_dx else torch.empty_like(x)
         g = {k: torch.empty_like(v, dtype=torch.float32) for k, v in
              dict(conv_w=conv_w, conv_b=conv_b, gn_w=gn_w, gn_b=gn_b, gate_w=gate_w, gate_b=gate_b).items()}
         ws = workspace(lib.frl_tcn_hot_bwd_workspace_bytes(npix), dev)
