@@ -100,6 +100,8 @@ int frl_conv3x3_bwd_weight(const void* dy, const void* y, int act, const void* x
 /* Test / A-B hook (no reference counterpart): 1 routes every 3x3 weight gradient through the generic kernel instead of the bf16
  * band kernel; returns the previous setting. */
 int frl_conv3x3_wgrad_force_generic(int on);
+/* Test / A-B hook: 0 = conv3x3 forward / bwd-data on 16-row tiles only (default 1: bf16 images of >= 32 rows take 32 x 16 tiles); returns the previous setting. */
+int frl_conv3x3_tile32(int on);
 
 /* ---- GroupNorm over NHWC rows ----------------------------------------------------------------------------------
  * nn.GroupNorm(G, C), eps 1e-5, per-sample statistics: frl/models/conv2d_encoder.py:117 (ReLU fused when relu=1,

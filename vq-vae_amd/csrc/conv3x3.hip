@@ -101,25 +101,25 @@ __global__ void c3_pack_kernel(typename DT<T>::frag_t* __restrict__ dst, const f
   }
 }
 
-#define C3F_TH 16      // forward / bwd_data tile: 16 x 16 pixels, 8 waves x 2 rows (2 waves per SIMD)
+#define C3F_TH 16      // forward / bwd_data tile: 16 x 16 pixels, 8 waves x 2 rows (2 waves per SIMD); the TH = 32 instantiation: 32 x 16, 4 rows per wave
 
 // Halo staging split in two so that the global loads of the NEXT stage fly behind the MFMA taps of the current one:
 //   c3_halo_fetch : issues every 16-byte load of the (TH+2) x 18 x CK halo into registers (zero padding resolved by predication)
 //   c3_halo_commit: applies the optional activation-derivative mask and writes the registers into the LDS halo
-template <typename T, int CK, int NTHR>
+template <typename T, int CK, int NTHR, int TH = C3F_TH, bool MASK = true>
 struct C3Halo {
   static constexpr int V = DT<T>::VEC;
   static constexpr int VPC = CK / V;
-  static constexpr int TOTAL = (C3F_TH + 2) * C3_WP * VPC;
+  static constexpr int TOTAL = (TH + 2) * C3_WP * VPC;
   static constexpr int ITEMS = (TOTAL + NTHR - 1) / NTHR;
   typedef typename std::conditional<sizeof(T) == 2, bf16x8, f32x4>::type vec_t;
-  vec_t x[ITEMS], m[ITEMS];
+  vec_t x[ITEMS], m[MASK ? ITEMS : 1];
 };
 
-template <typename T, int CK, int NTHR>
-__device__ __forceinline__ void c3_halo_fetch(C3Halo<T, CK, NTHR>& h, const T* __restrict__ X, const T* __restrict__ M, int b, int y0, int x0,
+template <typename T, int CK, int NTHR, int TH, bool MASK>
+__device__ __forceinline__ void c3_halo_fetch(C3Halo<T, CK, NTHR, TH, MASK>& h, const T* __restrict__ X, const T* __restrict__ M, int b, int y0, int x0,
                                               int H, int W, int C, int ck, int tid) {
-  typedef C3Halo<T, CK, NTHR> HT;
+  typedef C3Halo<T, CK, NTHR, TH, MASK> HT;
   typedef typename HT::vec_t vec_t;
 #pragma unroll
   for (int u = 0; u < HT::ITEMS; ++u) {
@@ -132,14 +132,16 @@ __device__ __forceinline__ void c3_halo_fetch(C3Halo<T, CK, NTHR>& h, const T* _
     vec_t v = *reinterpret_cast<const vec_t*>(X + off);
     if (!ok) v = vec_t{};
     h.x[u] = v;
-    if (M != nullptr) h.m[u] = *reinterpret_cast<const vec_t*>(M + off);
+    if constexpr (MASK) {
+      if (M != nullptr) h.m[u] = *reinterpret_cast<const vec_t*>(M + off);
+    }
   }
 }
 
-template <typename T, int CK, int NTHR>
-__device__ __forceinline__ void c3_halo_commit(const C3Halo<T, CK, NTHR>& h, T* __restrict__ halo, int pitch, bool has_mask, int mask_act,
+template <typename T, int CK, int NTHR, int TH, bool MASK>
+__device__ __forceinline__ void c3_halo_commit(const C3Halo<T, CK, NTHR, TH, MASK>& h, T* __restrict__ halo, int pitch, bool has_mask, int mask_act,
                                                int tid) {
-  typedef C3Halo<T, CK, NTHR> HT;
+  typedef C3Halo<T, CK, NTHR, TH, MASK> HT;
   typedef typename HT::vec_t vec_t;
 #pragma unroll
   for (int u = 0; u < HT::ITEMS; ++u) {
@@ -147,9 +149,11 @@ __device__ __forceinline__ void c3_halo_commit(const C3Halo<T, CK, NTHR>& h, T* 
     if (i >= HT::TOTAL) continue;
     const int px = i / HT::VPC, c0 = (i % HT::VPC) * HT::V;
     vec_t v = h.x[u];
-    if (has_mask) {
+    if constexpr (MASK) {
+      if (has_mask) {
 #pragma unroll
-      for (int e = 0; e < HT::V; ++e) v[e] = from_f32<T>(to_f32(v[e]) * act_bwd_from_y(to_f32(h.m[u][e]), mask_act));
+        for (int e = 0; e < HT::V; ++e) v[e] = from_f32<T>(to_f32(v[e]) * act_bwd_from_y(to_f32(h.m[u][e]), mask_act));
+      }
     }
     *reinterpret_cast<vec_t*>(halo + px * pitch + c0) = v;
   }
@@ -158,7 +162,10 @@ __device__ __forceinline__ void c3_halo_commit(const C3Halo<T, CK, NTHR>& h, T* 
 #ifdef C3_STAMPS
 __device__ unsigned long long* c3_dbg;       // diagnostic build only (tools/diag/c3_stamps.hip)
 #endif
-template <typename T, int NF, bool EPI = false>
+// TH: tile height (16 or 32 rows of 16 pixels); a wave owns RPW = TH / 8 consecutive rows.  TH = 32 halves the barriers / halo commits per
+// pixel, doubles the MFMA burst a prefetched halo has to hide behind, and lets four rows share each weight fragment read (16 LDS
+// fragment reads per 32 MFMAs instead of 12 per 16); the tap look-ahead keeps both weight sets but only one extra row of pixel fragments.
+template <typename T, int NF, bool EPI = false, int TH = C3F_TH, bool MASK = true>
 __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, const T* __restrict__ Xmask, int mask_act,
                                                       const typename DT<T>::frag_t* __restrict__ Wpk,
                                                       const float* __restrict__ bias, T* __restrict__ Y, int B, int H, int W,
@@ -172,12 +179,13 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
   constexpr int pitch = CK + C3<T>::PADE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* halo = reinterpret_cast<T*>(smem);
-  frag_t* wl = reinterpret_cast<frag_t*>(smem + (size_t)(C3F_TH + 2) * C3_WP * pitch * sizeof(T));
+  constexpr int RPW = TH / 8;
+  frag_t* wl = reinterpret_cast<frag_t*>(smem + (size_t)(TH + 2) * C3_WP * pitch * sizeof(T));
   float* bias_l = reinterpret_cast<float*>(wl + 9 * 4 * NF * 64);   // [Cout padded to 16] (zeros without a bias)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, kc = lane >> 4;
   for (int i = tid; i < ((Cout + 15) & ~15); i += 512) bias_l[i] = (bias != nullptr && i < Cout) ? bias[i] : 0.f;
-  const int tiles_x = (W + C3_TW - 1) / C3_TW, tiles_y = (H + C3F_TH - 1) / C3F_TH;
+  const int tiles_x = (W + C3_TW - 1) / C3_TW, tiles_y = (H + TH - 1) / TH;
   const int ntiles = B * tiles_x * tiles_y;
   const int MB = (Cout + 15) >> 4, qo = 4 * MB;
   const int nck = (Cin + CK - 1) / CK, noc = (MB + 3) / 4;
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
   const int my_tiles = bid0 < ntiles ? (ntiles - bid0 + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   const int per_tile = noc * nck, nstage = my_tiles * per_tile;
   int wl_block = -1;                                             // packed-weight block currently resident in LDS
-  C3Halo<T, CK, 512> hreg;
+  C3Halo<T, CK, 512, TH, MASK> hreg;
 #ifdef C3_STAMPS
   __shared__ unsigned long long c3_ts[8][8];
   if (tid < 64) (&c3_ts[0][0])[tid] = 0ull;
@@ -203,15 +211,15 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
     const int bid = bid0 + ti * (int)gridDim.x;
     b = bid / (tiles_x * tiles_y);
     const int tyx = bid % (tiles_x * tiles_y);
-    y0 = (tyx / tiles_x) * C3F_TH; x0 = (tyx % tiles_x) * C3_TW;
+    y0 = (tyx / tiles_x) * TH; x0 = (tyx % tiles_x) * C3_TW;
     oc_i = r / nck; ck_i = r % nck;
   };
   if (fast && nstage > 0) {
     int b, y0, x0, oc_i, ck_i;
     stage_geom(0, b, y0, x0, oc_i, ck_i);
-    c3_halo_fetch<T, CK, 512>(hreg, X, Xmask, b, y0, x0, H, W, Cin, ck_i * CK, tid);
+    c3_halo_fetch<T, CK, 512, TH, MASK>(hreg, X, Xmask, b, y0, x0, H, W, Cin, ck_i * CK, tid);
   }
-  f32x4 acc[2][4];
+  f32x4 acc[RPW][4];
   for (int st = 0; st < nstage; ++st) {
     int b, y0, x0, oc_i, ck_i;
     stage_geom(st, b, y0, x0, oc_i, ck_i);
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
     const int nmb = (MB - oc0) < 4 ? (MB - oc0) : 4;
     if (ck_i == 0) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < RPW; ++t)
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -227,8 +235,8 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
       C3_ST(0);                                                  // (epilogue + loop overhead of the previous stage)
       __syncthreads();                                           // the previous stage is done with halo / wl
       C3_ST(1);
-      if (fast) c3_halo_commit<T, CK, 512>(hreg, halo, pitch, has_mask, mask_act, tid);
-      else stage_halo<T, C3F_TH, 512>(halo, pitch, X, Xmask, mask_act, b, y0, x0, H, W, Cin, ck, CK, tid);
+      if (fast) c3_halo_commit<T, CK, 512, TH, MASK>(hreg, halo, pitch, has_mask, mask_act, tid);
+      else stage_halo<T, TH, 512>(halo, pitch, X, Xmask, mask_act, b, y0, x0, H, W, Cin, ck, CK, tid);
       // weights of this (out-chunk, in-chunk): wl[((tap*4 + m)*NF + s)*64 + lane], copied from the packed image
       const int blk = oc_i * nck + ck_i;
       if (blk != wl_block) {
@@ -241,38 +249,76 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
       if (fast && st + 1 < nstage) {                             // next stage's halo loads fly behind this stage's MFMA taps
         int b2, y2, x2, oc2, ck2;
         stage_geom(st + 1, b2, y2, x2, oc2, ck2);
-        c3_halo_fetch<T, CK, 512>(hreg, X, Xmask, b2, y2, x2, H, W, Cin, ck2 * CK, tid);
+        c3_halo_fetch<T, CK, 512, TH, MASK>(hreg, X, Xmask, b2, y2, x2, H, W, Cin, ck2 * CK, tid);
       }
       // 9 taps, software-pipelined: the LDS fragments of tap+1 are requested before the MFMAs of tap are issued
-      frag_t bfr[2][2][NF], afr[2][4][NF];
-      auto tap_load = [&](int tap, int buf) {
-        const int dy = tap / 3, dx = tap % 3;
+      if constexpr (RPW == 2) {
+        frag_t bfr[2][2][NF], afr[2][4][NF];
+        auto tap_load = [&](int tap, int buf) {
+          const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const T* hp = halo + ((2 * wave + t + dy) * C3_WP + px + dx) * pitch + q * kc;
+          for (int t = 0; t < 2; ++t) {
+            const T* hp = halo + ((2 * wave + t + dy) * C3_WP + px + dx) * pitch + q * kc;
 #pragma unroll
-          for (int s = 0; s < NF; ++s) {
-            if constexpr (FE == 8) bfr[buf][t][s] = *reinterpret_cast<const bf16x8*>(hp + 8 * s);
-            else bfr[buf][t][s] = hp[s];
+            for (int s = 0; s < NF; ++s) {
+              if constexpr (FE == 8) bfr[buf][t][s] = *reinterpret_cast<const bf16x8*>(hp + 8 * s);
+              else bfr[buf][t][s] = hp[s];
+            }
+          }
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int s = 0; s < NF; ++s) afr[buf][m][s] = wl[((tap * 4 + m) * NF + s) * 64 + lane];
+        };
+        tap_load(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int cur = tap & 1;
+          if (tap + 1 < 9) tap_load(tap + 1, cur ^ 1);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            if (m < nmb) {
+#pragma unroll
+              for (int s = 0; s < NF; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t][m] = mfma16(afr[cur][m][s], bfr[cur][t][s], acc[t][m]);
+            }
           }
         }
+      } else {
+        // 4 rows per wave: the weight fragments of a tap serve four rows; look-ahead = the next (tap, row)'s pixel fragments and, behind the
+        // last row of a tap, the next tap's weight fragments
+        frag_t bfr[2][NF], afr[2][4][NF];
+        auto b_load = [&](int step, int buf) {                    // step = tap * RPW + row
+          const int tap = step / RPW, t = step % RPW;
+          const int dy = tap / 3, dx = tap % 3;
+          const T* hp = halo + ((RPW * wave + t + dy) * C3_WP + px + dx) * pitch + q * kc;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+          for (int s = 0; s < NF; ++s) {
+            if constexpr (FE == 8) bfr[buf][s] = *reinterpret_cast<const bf16x8*>(hp + 8 * s);
+            else bfr[buf][s] = hp[s];
+          }
+        };
+        auto a_load = [&](int tap, int buf) {
 #pragma unroll
-          for (int s = 0; s < NF; ++s) afr[buf][m][s] = wl[((tap * 4 + m) * NF + s) * 64 + lane];
-      };
-      tap_load(0, 0);
+          for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int cur = tap & 1;
-        if (tap + 1 < 9) tap_load(tap + 1, cur ^ 1);
+            for (int s = 0; s < NF; ++s) afr[buf][m][s] = wl[((tap * 4 + m) * NF + s) * 64 + lane];
+        };
+        a_load(0, 0);
+        b_load(0, 0);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          if (m < nmb) {
+        for (int step = 0; step < 9 * RPW; ++step) {
+          const int tap = step / RPW, t = step % RPW, cb = step & 1, ca = tap & 1;
+          __builtin_amdgcn_sched_barrier(0);                      // (one step of look-ahead, not more: hoisted further the fragments spill)
+          if (step + 1 < 9 * RPW) b_load(step + 1, cb ^ 1);
+          if (t == 0 && tap + 1 < 9) a_load(tap + 1, ca ^ 1);
 #pragma unroll
-            for (int s = 0; s < NF; ++s)
+          for (int m = 0; m < 4; ++m) {
+            if (m < nmb) {
 #pragma unroll
-              for (int t = 0; t < 2; ++t) acc[t][m] = mfma16(afr[cur][m][s], bfr[cur][t][s], acc[t][m]);
+              for (int s = 0; s < NF; ++s) acc[t][m] = mfma16(afr[ca][m][s], bfr[cb][s], acc[t][m]);
+            }
           }
         }
       }
@@ -282,8 +328,8 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
     // epilogue: bias comes from the LDS copy made at kernel start; when the lane's 16 output channels are contiguous
     // (Cout a multiple of 64) they leave as two 16-byte stores per pixel (bf16) instead of four 8-byte ones
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int gy = y0 + 2 * wave + t, gx = x0 + px;
+    for (int t = 0; t < RPW; ++t) {
+      const int gy = y0 + RPW * wave + t, gx = x0 + px;
       if (gy >= H || gx >= W) continue;
       T* yp = Y + (((int64_t)b * H + gy) * W + gx) * Cout;
       if (nmb == 4 && (MB & 3) == 0 && (Cout & 63) == 0) {
@@ -545,6 +591,8 @@ struct C3Epi {
 // ------------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------------
+static int g_c3_tile32 = 1;      // test hook (frl_conv3x3_tile32): 0 = always the 16-row tile
+
 template <typename T, int NF>
 static int launch_c3(const void* x, const void* xm, int mask_act, const float* w, int64_t so, int64_t si, int tap_rev,
                      const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act, void* ws, size_t ws_bytes,
@@ -561,13 +609,19 @@ static int launch_c3(const void* x, const void* xm, int mask_act, const float* w
     if (void* img = frl_pack_cached(&job, 1, nfrag * sizeof(frag_t), &hit)) pk = (const frag_t*)img;
     if (!hit) FRL_LAUNCH((c3_pack_kernel<T, NF>), dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, (frag_t*)pk, w, so, si, tap_rev, Cin, Cout);
   }
-  const size_t lds = (size_t)(C3F_TH + 2) * C3_WP * (CK + C3<T>::PADE) * sizeof(T) + (size_t)9 * 4 * NF * 64 * sizeof(frag_t) +
-                     (size_t)((Cout + 15) / 16 * 16) * sizeof(float);
+  // tile height: 32 rows (4 per wave) where the image has them and the taller halo still fits the LDS next to the 9-tap weight block
+  const size_t lds_w = (size_t)9 * 4 * NF * 64 * sizeof(frag_t) + (size_t)((Cout + 15) / 16 * 16) * sizeof(float);
+  const size_t lds32 = (size_t)(32 + 2) * C3_WP * (CK + C3<T>::PADE) * sizeof(T) + lds_w;
+  const bool tall = g_c3_tile32 && sizeof(T) == 2 && H >= 32 && lds32 <= 160 * 1024;
+  const int TH = tall ? 32 : C3F_TH;
+  const size_t lds = tall ? lds32 : (size_t)(C3F_TH + 2) * C3_WP * (CK + C3<T>::PADE) * sizeof(T) + lds_w;
   if (lds > 160 * 1024) return frl_fail(-3, "conv3x3: LDS budget exceeded");
   const bool epi = yadd != nullptr || y2 != nullptr;            // the epilogue extras are their own instantiation: the plain one keeps its registers
-  auto kern = epi ? conv3x3_kernel<T, NF, true> : conv3x3_kernel<T, NF, false>;
+  // (the 32-row tile keeps the halo prefetch of a convolution without an activation mask -- every forward call -- to half the registers)
+  auto kern = tall ? (epi ? conv3x3_kernel<T, NF, true, 32, true> : (xm != nullptr ? conv3x3_kernel<T, NF, false, 32, true> : conv3x3_kernel<T, NF, false, 32, false>))
+                   : (epi ? conv3x3_kernel<T, NF, true, C3F_TH> : conv3x3_kernel<T, NF, false, C3F_TH>);
   FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int tiles = B * ((H + C3F_TH - 1) / C3F_TH) * ((W + C3_TW - 1) / C3_TW);
+  const int tiles = B * ((H + TH - 1) / TH) * ((W + C3_TW - 1) / C3_TW);
   const int grid = tiles < 256 ? tiles : 256;                  // LDS allows one workgroup per CU: persistent over the tiles
   FRL_LAUNCH_AS("conv3x3_kernel", kern, dim3(grid), dim3(512), lds, st, (const T*)x, (const T*)xm, mask_act, pk, bias, (T*)y, B,
                      H, W, Cin, Cout, act, (const T*)yadd, (const T*)ysub, (T*)y2);
@@ -601,6 +655,10 @@ int c3v_launch(const void* dy, const void* ym, int act, const void* x, float* ws
                hipStream_t st);
 
 extern "C" {
+
+// test / A-B hook: 0 = the forward / bwd-data kernel always takes the 16-row tile (default 1: 32-row tiles for bf16 images of >= 32 rows)
+int frl_conv3x3_tile32(int on) { const int was = g_c3_tile32; g_c3_tile32 = on ? 1 : 0; return was; }
+
 
 // x [B][H][W][Cin], w [Cout][Cin][3][3] f32, bias [Cout] f32 or null, y [B][H][W][Cout]
 int frl_conv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,

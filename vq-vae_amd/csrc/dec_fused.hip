@@ -197,29 +197,27 @@ __global__ __launch_bounds__(64 * NW) void dec_mse_bwd_kernel(const TT* __restri
   const bf16x8 ones = (r16 == 0) ? bf16x8{one, one, one, one, one, one, one, one} : bf16x8{zero, zero, zero, zero, zero, zero, zero, zero};
 
   const int64_t nwt = (P + R - 1) / R;
-  // the next round's rows are requested before this round's chain and stay in flight across its weight-gradient phase
-  LQTile<TT, NFZ> zt, zn;
-  LQTile<TT, 2> tt, tn;
-  {
-    const int64_t w0 = (int64_t)blockIdx.x < nwt ? (int64_t)blockIdx.x : 0;
-    const int64_t r0 = w0 * R + prow;
+  // The rows of the next THREE rounds are in flight while a round computes: the workgroup is alone on its CU (LDS) and a round's rows
+  // are only ~19 KB, so one round of look-ahead left the kernel bound by memory latency (19 KB per ~3 us per CU = 1.3 TB/s over the chip).
+  LQTile<TT, NFZ> zt, z1, z2, zn;
+  LQTile<TT, 2> tt, t1, t2, tn;
+  auto fetch = [&](LQTile<TT, NFZ>& zz, LQTile<TT, 2>& tg, int64_t w) {
+    const int64_t wc = w < nwt ? w : (nwt - 1);
+    const int64_t r0 = wc * R + prow;
     const int64_t rc = r0 < P ? r0 : P - 1;
-    lq_load<TT, NFZ>(zt, Z, rc, Cz, kc, fastz);
-    lq_load<TT, 2>(tt, TGT, rc, DF_F, kc, true);
-  }
+    lq_load<TT, NFZ>(zz, Z, rc, Cz, kc, fastz);
+    lq_load<TT, 2>(tg, TGT, rc, DF_F, kc, true);
+  };
+  fetch(zt, tt, (int64_t)blockIdx.x);
+  fetch(z1, t1, (int64_t)blockIdx.x + gridDim.x);
+  fetch(z2, t2, (int64_t)blockIdx.x + 2 * (int64_t)gridDim.x);
   for (int64_t wt = blockIdx.x; wt < nwt; wt += gridDim.x) {
     int64_t row = wt * R + prow;
     const bool inb = row < P;
     bool valid = inb;
     if (!inb) row = P - 1;
     if (valid && mask != nullptr) valid = mask[row] != 0;
-    {
-      const int64_t wn = wt + gridDim.x < nwt ? wt + gridDim.x : wt;
-      const int64_t rn = wn * R + prow;
-      const int64_t rc = rn < P ? rn : P - 1;
-      lq_load<TT, NFZ>(zn, Z, rc, Cz, kc, fastz);
-      lq_load<TT, 2>(tn, TGT, rc, DF_F, kc, true);
-    }
+    fetch(zn, tn, wt + 3 * (int64_t)gridDim.x);
     float h[32], xh[16];
     LQTile<TT, 4> ht;
     dec_chain<NFZ>(h, xh, zt, w1, w2, b1q, b2q, ht, lane);
@@ -292,8 +290,8 @@ __global__ __launch_bounds__(64 * NW) void dec_mse_bwd_kernel(const TT* __restri
       }
     }
     __syncthreads();
-    zt = zn;
-    tt = tn;
+    zt = z1; z1 = z2; z2 = zn;
+    tt = t1; t1 = t2; t2 = tn;
   }
   float* my = slab + (int64_t)blockIdx.x * (DF_F * DF_H + DF_H * CZP + DF_F + DF_H);
 #pragma unroll

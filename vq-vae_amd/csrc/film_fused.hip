@@ -310,7 +310,7 @@ int frl_film_fused_supported(int cond_dim, int hidden, int target_dim, int dtype
   return (dtype == FRL_BF16 && cond_dim == FF_CZ && hidden == FF_HID && target_dim == FF_C) ? 1 : 0;
 }
 
-size_t frl_film_fused_workspace_bytes(void) { return (size_t)FF_FR_BWD * sizeof(frag8) + 256 + (size_t)256 * FF_SLAB * sizeof(float); }
+size_t frl_film_fused_workspace_bytes(void) { return (size_t)FF_FR_BWD * sizeof(frag8) + 256 + (size_t)768 * FF_SLAB * sizeof(float); }
 
 // z_type [B][HW][64] (stop-gradient input), h [B][T][HW][12] bf16; w1g / w1b [32][64], w2g / w2b [12][32] f32 with their biases
 // -> z [B][T][HW][12] = gamma * h + beta, gamma / beta [B][HW][12] bf16
@@ -342,7 +342,7 @@ int frl_film_fused_bwd(const void* z_type, const void* h, const void* dz, const 
   const frag8* pk = ff_packed(w1g, w1b, w2g, w2b, 1, reinterpret_cast<frag8*>(w), stream);
   float* slab = reinterpret_cast<float*>(w + pkb);
   int64_t g = (npix + FFB_R - 1) / FFB_R;
-  if (g > 256) g = 256;
+  if (g > 768) g = 768;                                         // 47 KB of LDS: three workgroups per CU hide each other's row loads
   const size_t lds = (size_t)FF_FR_BWD * sizeof(frag8) + 96 * sizeof(float) + (size_t)FFB_R * (3 * FFB_P64 + FFB_P32) * sizeof(bf16);
   FRL_LAUNCH(film_fused_bwd_kernel, dim3((unsigned)g), dim3(256), lds, stream, (const bf16*)z_type, (const bf16*)h, (const bf16*)dz, pk, b1g, b1b, b2g,
              b2b, (bf16*)dh, slab, npix, HW, T);

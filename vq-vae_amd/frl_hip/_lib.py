@@ -42,6 +42,7 @@ SIGNATURES = {
     "frl_conv1x1_bwd_data_add": (c_int, [P, P, I, P, P, P, L, I, I, I, P, S, P]),
     "frl_wgrad_set_max_workgroups": (c_int, [I]),
     "frl_conv3x3_wgrad_force_generic": (c_int, [I]),
+    "frl_conv3x3_tile32": (c_int, [I]),
     "frl_conv1x1_bwd_weight_workspace_bytes": (S, [L, I, I]),
     "frl_conv1x1_bwd_weight": (c_int, [P, P, I, P, P, P, L, I, I, I, P, S, P]),
     "frl_conv_tap_bwd_weight": (c_int, [P, P, I, P, P, L, L, P, L, I, I, I, I, I, I, P, S, I, P]),
