@@ -86,6 +86,11 @@ int frl_conv_tap_bwd_weight(const void* dy, const void* y, int act, const void* 
  * x [B][H][W][Cin], w [Cout][Cin][3][3]. */
 int frl_conv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
                     int act, int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
+/* gate_net's second convolution with the blend in its epilogue (spatial.py:332-335 at min_gate = 0): gate = sigmoid(conv3x3(x) + bias),
+ * out = smoothed + gate * residual.  One launch instead of the convolution + frl_gate_blend_fwd. */
+int frl_conv3x3_fwd_gate_blend(const void* x, const float* w, const float* bias, const void* smoothed, const void* residual, void* gate,
+                               void* out, int B, int H, int W, int Cin, int Cout, int dtype, void* ws, size_t ws_bytes,
+                               frl_stream_t stream);
 int frl_conv3x3_bwd_data(const void* dy, const void* y, int act, const float* w, void* dx, int B, int H, int W, int Cin,
                          int Cout, int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
 /* frl_conv3x3_bwd_data with epilogue extras: dx = conv(...) + add (add may be null); with the pair sub_from / out2 (both or neither)

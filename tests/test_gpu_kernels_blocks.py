@@ -701,6 +701,15 @@ def test_backward_epilogue_sums_match_separate_launches(dtype, tol):
         dx3, out3 = ops.conv3x3_bwd_data(dy, w, y, ACT_RELU, sub_from=sub)
         assert (dx3.float() - plain).abs().max().item() <= tol * scale
         assert (out3.float() - (sub.float() - dx3.float())).abs().max().item() <= tol * scale
+    # gate blend in the epilogue of the sigmoid convolution == the convolution followed by the stand-alone blend kernel (min_gate = 0), bit for bit
+    for (B, H, W, cin, cout) in [(2, 32, 32, 64, 64), (1, 9, 11, 12, 8)]:
+        w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).to(DEV)
+        bias = torch.randn(cout, generator=g).to(DEV)
+        x, sm, res = rnd(B, H, W, cin), rnd(B, H, W, cout), rnd(B, H, W, cout)
+        graw = ops.conv3x3_fwd(x, w, bias, ops.ACT_SIGMOID)
+        out_ref, gate_ref = ops.gate_blend_fwd(sm, res, graw, 0.0)
+        out, gate = ops.conv3x3_fwd_gate_blend(x, w, bias, sm, res)
+        assert torch.equal(gate, graw) and torch.equal(gate, gate_ref) and torch.equal(out, out_ref)
     for (P, cin, cout) in [(4096, 64, 32), (333, 12, 20), (1000, 64, 256), (130, 8, 4)]:
         w = (torch.randn(cout, cin, generator=g) * 0.2).to(DEV)
         dy, add = rnd(P, cout), rnd(P, cin)

@@ -170,9 +170,11 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
                                                       const typename DT<T>::frag_t* __restrict__ Wpk,
                                                       const float* __restrict__ bias, T* __restrict__ Y, int B, int H, int W,
                                                       int Cin, int Cout, int act, const T* __restrict__ Yadd,
-                                                      const T* __restrict__ Ysub, T* __restrict__ Y2) {
-  // Yadd (optional): Y = act(conv + bias) + Yadd.  Ysub/Y2 (optional pair): Y2 = Ysub - Y.  Both ride in the epilogue so that a
+                                                      const T* __restrict__ Ysub, T* __restrict__ Y2, int epi_mode) {
+  // epi_mode 0: Yadd (optional): Y = act(conv + bias) + Yadd.  Ysub/Y2 (optional pair): Y2 = Ysub - Y.  Both ride in the epilogue so that a
   // backward pass can fold the gradient accumulation of a tensor with two consumers into the convolution that produces one of them.
+  // epi_mode 1 (gate blend of EdgeAwareSmoothingConv2D, spatial.py:332-335 with min_gate = 0): Y = gate = act(conv + bias) and
+  // Y2 = Yadd + gate * Ysub (Yadd = smoothed, Ysub = residual; gate taken as rounded for its store, as the stand-alone kernel reads it).
   typedef typename DT<T>::frag_t frag_t;
   constexpr int FE = DT<T>::FE;
   constexpr int q = NF * FE, CK = 4 * q;
@@ -352,6 +354,16 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
             float o[DT<T>::VEC];
 #pragma unroll
             for (int e = 0; e < DT<T>::VEC; ++e) o[e] = v[j + e];
+            if (epi_mode == 1) {
+              Vec<T>::store(Y + yo + j, o);
+              float a[DT<T>::VEC], r[DT<T>::VEC];
+              Vec<T>::load(Yadd + yo + j, a);
+              Vec<T>::load(Ysub + yo + j, r);
+#pragma unroll
+              for (int e = 0; e < DT<T>::VEC; ++e) a[e] = fmaf(to_f32(from_f32<T>(o[e])), r[e], a[e]);
+              Vec<T>::store(Y2 + yo + j, a);
+              continue;
+            }
             if (Yadd != nullptr) {
               float a[DT<T>::VEC];
               Vec<T>::load(Yadd + yo + j, a);
@@ -389,6 +401,12 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (cb + r >= Cout) continue;
+            if (epi_mode == 1) {
+              const T o = from_f32<T>(v[r]);
+              yp[cb + r] = o;
+              Y2[yo + cb + r] = from_f32<T>(fmaf(to_f32(o), to_f32(Ysub[yo + cb + r]), to_f32(Yadd[yo + cb + r])));
+              continue;
+            }
             if (Yadd != nullptr) v[r] += to_f32(Yadd[yo + cb + r]);
             const T o = from_f32<T>(v[r]);
             yp[cb + r] = o;
@@ -596,7 +614,7 @@ static int g_c3_tile32 = 1;      // test hook (frl_conv3x3_tile32): 0 = always t
 template <typename T, int NF>
 static int launch_c3(const void* x, const void* xm, int mask_act, const float* w, int64_t so, int64_t si, int tap_rev,
                      const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act, void* ws, size_t ws_bytes,
-                     hipStream_t st, const void* yadd = nullptr, const void* ysub = nullptr, void* y2 = nullptr) {
+                     hipStream_t st, const void* yadd = nullptr, const void* ysub = nullptr, void* y2 = nullptr, int epi_mode = 0) {
   typedef typename DT<T>::frag_t frag_t;
   constexpr int CK = 4 * NF * DT<T>::FE;
   const int MBt = (Cout + 15) / 16;
@@ -624,21 +642,21 @@ static int launch_c3(const void* x, const void* xm, int mask_act, const float* w
   const int tiles = B * ((H + TH - 1) / TH) * ((W + C3_TW - 1) / C3_TW);
   const int grid = tiles < 256 ? tiles : 256;                  // LDS allows one workgroup per CU: persistent over the tiles
   FRL_LAUNCH_AS("conv3x3_kernel", kern, dim3(grid), dim3(512), lds, st, (const T*)x, (const T*)xm, mask_act, pk, bias, (T*)y, B,
-                     H, W, Cin, Cout, act, (const T*)yadd, (const T*)ysub, (T*)y2);
+                     H, W, Cin, Cout, act, (const T*)yadd, (const T*)ysub, (T*)y2, epi_mode);
   return frl_check_launch("conv3x3");
 }
 
 static int c3_dispatch(const void* x, const void* xm, int mask_act, const float* w, int64_t so, int64_t si, int tap_rev,
                        const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act, int dtype, void* ws, size_t ws_bytes,
-                       hipStream_t st, const void* yadd = nullptr, const void* ysub = nullptr, void* y2 = nullptr) {
+                       hipStream_t st, const void* yadd = nullptr, const void* ysub = nullptr, void* y2 = nullptr, int epi_mode = 0) {
   if (B <= 0 || H <= 0 || W <= 0) return frl_fail(-2, "conv3x3: empty input");
   if ((ysub == nullptr) != (y2 == nullptr)) return frl_fail(-2, "conv3x3: sub_from and out2 come as a pair");
   if (dtype == FRL_F32) {
-    if (Cin <= 16) return launch_c3<float, 4>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st, yadd, ysub, y2);
-    return launch_c3<float, 8>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st, yadd, ysub, y2);
+    if (Cin <= 16) return launch_c3<float, 4>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st, yadd, ysub, y2, epi_mode);
+    return launch_c3<float, 8>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st, yadd, ysub, y2, epi_mode);
   } else if (dtype == FRL_BF16) {
-    if (Cin <= 32) return launch_c3<bf16, 1>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st, yadd, ysub, y2);
-    return launch_c3<bf16, 2>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st, yadd, ysub, y2);
+    if (Cin <= 32) return launch_c3<bf16, 1>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st, yadd, ysub, y2, epi_mode);
+    return launch_c3<bf16, 2>(x, xm, mask_act, w, so, si, tap_rev, bias, y, B, H, W, Cin, Cout, act, ws, ws_bytes, st, yadd, ysub, y2, epi_mode);
   }
   return frl_fail(-2, "conv3x3: bad dtype");
 }
@@ -664,6 +682,15 @@ int frl_conv3x3_tile32(int on) { const int was = g_c3_tile32; g_c3_tile32 = on ?
 int frl_conv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
                     int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
   return c3_dispatch(x, nullptr, 0, w, (int64_t)Cin * 9, 9, 0, bias, y, B, H, W, Cin, Cout, act, dtype, ws, ws_bytes, stream);
+}
+
+// The second gate convolution of EdgeAwareSmoothingConv2D with the blend in its epilogue (spatial.py:332-335, min_gate = 0):
+// gate = sigmoid(conv3x3(x, w) + bias), out = smoothed + gate * residual; smoothed / residual / gate / out [B][H][W][Cout].
+int frl_conv3x3_fwd_gate_blend(const void* x, const float* w, const float* bias, const void* smoothed, const void* residual, void* gate, void* out,
+                               int B, int H, int W, int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (smoothed == nullptr || residual == nullptr || out == nullptr) return frl_fail(-2, "conv3x3_fwd_gate_blend: smoothed, residual and out are required");
+  return c3_dispatch(x, nullptr, 0, w, (int64_t)Cin * 9, 9, 0, bias, gate, B, H, W, Cin, Cout, FRL_ACT_SIGMOID, dtype, ws, ws_bytes, stream, smoothed,
+                     residual, out, 1);
 }
 
 // dx = conv3x3(dy .* act'(y), w^T flipped)

@@ -90,6 +90,7 @@ SIGNATURES = {
     "frl_host_parallel_copy": (c_int, [P, P, S, I]),
     "frl_normalize_chunk_tiles": (c_int, [P, I, I, I, I, I, P, I, I, P, P, I, P, P]),
     "frl_conv3x3_fwd": (c_int, [P, P, P, P, I, I, I, I, I, I, I, P, S, P]),
+    "frl_conv3x3_fwd_gate_blend": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, P, S, P]),
     "frl_conv3x3_bwd_data": (c_int, [P, P, I, P, P, I, I, I, I, I, I, P, S, P]),
     "frl_conv3x3_bwd_data_fused": (c_int, [P, P, I, P, P, P, P, P, I, I, I, I, I, I, P, S, P]),
     "frl_conv3x3_bwd_weight_workspace_bytes": (S, [I, I, I, I, I]),

@@ -202,8 +202,12 @@ class SpatialSmoothFn(Function):
             b_logit = ops.conv1x1_fwd(feat, w_b, b_b, ACT_NONE)
             sm, res, a_soft, b_soft = ops.edge_smooth_fwd(x, a_logit, b_logit, rank, dil)
         g1 = ops.conv3x3_fwd(res, w_g0, b_g0, ACT_RELU)
-        gate_raw = ops.conv3x3_fwd(g1, w_g2, b_g2, ACT_SIGMOID)
-        out, gate = ops.gate_blend_fwd(sm, res, gate_raw, min_gate)
+        if min_gate <= 0.0 and b_g2 is not None and ops.fusion_enabled("blend"):
+            out, gate_raw = ops.conv3x3_fwd_gate_blend(g1, w_g2, b_g2, sm, res)      # blend in the convolution's epilogue; no floor: gate IS gate_raw
+            gate = gate_raw
+        else:
+            gate_raw = ops.conv3x3_fwd(g1, w_g2, b_g2, ACT_SIGMOID)
+            out, gate = ops.gate_blend_fwd(sm, res, gate_raw, min_gate)
         ctx.cfg = (rank, dil, min_gate)
         ctx.has_bias = tuple(b is not None for b in (b_mb, b_a, b_b, b_g0, b_g2))
         ctx.set_materialize_grads(False)

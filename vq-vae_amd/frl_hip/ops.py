@@ -668,6 +668,24 @@ def conv3x3_fwd(x, w, bias, act: int = ACT_NONE):
     return y
 
 
+@_timed("conv3x3_fwd_gate_blend")
+def conv3x3_fwd_gate_blend(x, w, bias, smoothed, residual):
+    """-> (out = smoothed + gate * residual, gate = sigmoid(conv3x3(x, w) + bias)): the blend of spatial.py:332-335 (min_gate = 0) in the
+    convolution's epilogue."""
+    b, h, wd, cin = x.shape
+    cout = w.shape[0]
+    _chk_rows(x, cin, "conv3x3.x")
+    gate = torch.empty(b, h, wd, cout, dtype=x.dtype, device=x.device)
+    _chk_like(smoothed, gate, "conv3x3_fwd_gate_blend.smoothed")
+    _chk_like(residual, gate, "conv3x3_fwd_gate_blend.residual")
+    out = torch.empty_like(gate)
+    lib = _lib.load()
+    ws = workspace(lib.frl_conv_workspace_bytes(cin, cout, 9), x.device)
+    check(lib.frl_conv3x3_fwd_gate_blend(_p(x), _p(_f32(w, "w")), _p(_f32(bias, "bias")), _p(smoothed), _p(residual), _p(gate), _p(out), b, h, wd,
+                                         cin, cout, _dt(x), _p(ws), ws.numel(), _stream()), "frl_conv3x3_fwd_gate_blend")
+    return out, gate
+
+
 @_timed("conv3x3_bwd_data")
 def conv3x3_bwd_data(dy, w, y=None, act: int = ACT_NONE, add=None, sub_from=None):
     """dx = conv3x3^T(dy .* act'(y)) (+ add).  With sub_from the call returns (dx, sub_from - dx): both extras ride in the epilogue."""
