@@ -368,6 +368,29 @@ __device__ __forceinline__ double vq_exact_one(const T* __restrict__ Z, const fl
   return d0;
 }
 
+// The same float64 distance with both operands taken from LDS (bf16 rows with d = 4 q): z from the parked-row copy, e from the packed
+// image (e rounded to bf16 = -0.5 x the packed -2e, exact).  Same channel order and arithmetic as vq_exact_pair: same bits.
+template <int NF>
+__device__ __forceinline__ double vq_exact_lds(const bf16* __restrict__ zrow, const bf16x8* __restrict__ wl, int code, int d) {
+  constexpr int q = NF * 8;
+  double s0 = 0.0;
+  for (int j = 0; j < d; j += 8) {
+    const bf16x8 zv = *reinterpret_cast<const bf16x8*>(zrow + j);
+    const bf16x8 pv = wl[((code >> 4) * NF + ((j % q) >> 3)) * 64 + (code & 15) + 16 * (j / q)];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double da = (double)(float)zv[e] - (double)(-0.5f * (float)pv[e]);
+      s0 = __builtin_fma(da, da, s0);
+    }
+  }
+  return s0;
+}
+
+// Workgroup barrier of the batch loop: orders LDS traffic only.  __syncthreads() also drains the vector-memory queue, i.e. the first
+// barrier behind the epilogue waited for every z_q / index store of the batch to reach memory before the parked rows were looked at.
+#define VQ_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define VQ_PZ_CAP 16         // parked rows per batch whose z row is kept in LDS (the usual case: ~0.3-0.7 % of a batch's rows are parked)
+
 template <typename T, int NF, int NT, int NW>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_resident_kernel(
     const T* __restrict__ Z, const float* __restrict__ E, const float* __restrict__ en_g, int64_t N, int K, int d, int Kc,
@@ -387,6 +410,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_resident
   int* park = bestk + VQ_FAST_ROWS;                                                           // [BATCH] x {row - batch base, limit (f32 bits)}
   int* cand = park + 2 * BATCH;                                                               // [CAND_CAP] (slot << 16) | code
   int* misc = cand + CAND_CAP;                                                                // [0..NW) parked per wave, [16] candidates, [17] last flag, [18..18+NW) f32 maxima
+  T* park_z = reinterpret_cast<T*>(misc + 32);                                                // [VQ_PZ_CAP][d] rows of the parked vectors (bf16 fast path only)
   int32_t* counts_acc = reinterpret_cast<int32_t*>(ctl + 1);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vx = lane & 15, kc = lane >> 4;
@@ -586,11 +610,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_resident
     VQ_ST(4);                                                      // reduce, ambiguity test, z_q, histogram
     // ---- park the ambiguous rows in row order: slot = (rows parked by the waves before this one) + rank inside the wave ----
     if ((tide & 63) == 0) misc[tide >> 6] = nparked;
-    __syncthreads();
+    VQ_LDS_BARRIER();
     int pbase = 0, n = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) { const int c = misc[w]; if (w < (tide >> 6)) pbase += c; n += c; }
-    if (n == 0) { __syncthreads(); continue; }                     // (uniform) nothing to resolve in this batch
+    if (n == 0) { VQ_LDS_BARRIER(); continue; }                     // (uniform) nothing to resolve in this batch
     if (kce == 0) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -599,7 +623,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_resident
           park[2 * (pbase + rank[t]) + 1] = __float_as_int(lim[t]);
         }
     }
-    __syncthreads();
+    // bf16 rows, few of them parked (the usual case): their vectors go to LDS as well, straight from the registers of the four lanes
+    // that hold them; the screen, the float64 distances and the outputs below then touch no global memory but the final stores (the
+    // global-memory form of this pass was a chain of dependent L2 / HBM latencies behind barriers: ~9 us per batch)
+    bool zlds = false;
+    if constexpr (FE == 8) {
+      zlds = fast && n <= VQ_PZ_CAP;
+      if (zlds) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          if (((ambm >> t) & 1u) && v0e + t * 16 + vxe < N) {
+#pragma unroll
+            for (int s = 0; s < NF; ++s) *reinterpret_cast<bf16x8*>(park_z + (pbase + rank[t]) * d + q * kce + 8 * s) = zt[t].f[s];
+          }
+      }
+    }
+    VQ_LDS_BARRIER();
     bool all_waves = n <= VQ_FAST_ROWS;
     int tidr = tid;
     asm volatile("" : "+v"(tidr));
@@ -613,7 +652,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_resident
         const int64_t row = base + park[2 * (valid ? li : t0)];
         const float lm = __int_as_float(park[2 * (valid ? li : t0) + 1]);
         LQTile<T, NF> zr;
-        lq_load<T, NF>(zr, Z, row, d, kcr, fast);
+        bool from_lds = false;
+        if constexpr (FE == 8) {
+          if (zlds) {
+            from_lds = true;
+#pragma unroll
+            for (int s = 0; s < NF; ++s) zr.f[s] = *reinterpret_cast<const bf16x8*>(park_z + (valid ? li : t0) * d + q * kcr + 8 * s);
+          }
+        }
+        if (!from_lds) lq_load<T, NF>(zr, Z, row, d, kcr, fast);
         for (int mb = mb0; mb < mb1; ++mb) {
           f32x4 acc = *reinterpret_cast<const f32x4*>(enl + mb * 16 + 4 * kcr);
 #pragma unroll
@@ -628,7 +675,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_resident
           }
         }
       }
-      __syncthreads();
+      VQ_LDS_BARRIER();
       const int ncand = misc[16];
       all_waves = ncand <= CAND_CAP;                               // (uniform)
       if (all_waves) {
@@ -639,13 +686,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_resident
         if (c < ncand) {
           const int cv = cand[c];
           li = cv >> 16; code = cv & 0xffff;
-          const double dist = vq_exact_one<T>(Z, E, base + park[2 * li], code, d);
+          double dist;
+          bool done_ = false;
+          if constexpr (FE == 8) {
+            if (zlds) { dist = vq_exact_lds<NF>(reinterpret_cast<const bf16*>(park_z) + li * d, reinterpret_cast<const bf16x8*>(wl), code, d); done_ = true; }
+          }
+          if (!done_) dist = vq_exact_one<T>(Z, E, base + park[2 * li], code, d);
           bits = (unsigned long long)__double_as_longlong(dist);
           __hip_atomic_fetch_min(&best[li], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        __syncthreads();
+        VQ_LDS_BARRIER();
         if (c < ncand && bits == best[li]) __hip_atomic_fetch_min(&bestk[li], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __syncthreads();
+        VQ_LDS_BARRIER();
         // ---- outputs of the resolved rows: 16 lanes per row ----
         const int j = tidr & 15;
         for (int li2 = tidr >> 4; li2 < n; li2 += NW * 4) {
@@ -653,14 +705,26 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_resident
           if ((unsigned)bk >= (unsigned)K) bk = 0;                 // no candidate at all (NaN row): argmin of an all-NaN row is 0
           const int64_t row = base + park[2 * li2];
           for (int ch = j; ch < d; ch += 16) {
-            const float ev = to_f32(from_f32<T>(E[(int64_t)bk * d + ch]));
+            float ev, zv;
+            bool done_ = false;
+            if constexpr (FE == 8) {
+              if (zlds) {
+                ev = -0.5f * (float)reinterpret_cast<const bf16x8*>(wl)[((bk >> 4) * NF + ((ch % q) >> 3)) * 64 + (bk & 15) + 16 * (ch / q)][ch & 7];
+                zv = (float)reinterpret_cast<const bf16*>(park_z)[li2 * d + ch];
+                done_ = true;
+              }
+            }
+            if (!done_) {
+              ev = to_f32(from_f32<T>(E[(int64_t)bk * d + ch]));
+              zv = to_f32(Z[row * (int64_t)d + ch]);
+            }
             zq_out[row * (int64_t)d + ch] = from_f32<T>(ev);
-            const float df = to_f32(Z[row * (int64_t)d + ch]) - ev;
+            const float df = zv - ev;
             sq_acc = fmaf(df, df, sq_acc);
           }
           if (j == 0) { idx_out[row] = bk; atomicAdd(&hist[bk], 1); }
         }
-        __syncthreads();
+        VQ_LDS_BARRIER();
         if (tidr < VQ_FAST_ROWS && tidr < n) {
           int m1 = -1;
           asm volatile("" : "+v"(m1));                              // (materialised here, not carried through the batch loop)
@@ -728,7 +792,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_resident
       }
     }
     n_resolved += n;
-    __syncthreads();
+    VQ_LDS_BARRIER();
     if (tid == 0) misc[16] = 0;
     VQ_ST(5);                                                      // exact re-evaluation of the parked rows
   }
@@ -1315,7 +1379,7 @@ static int launch_vq(const void* z, const float* E, char* prep, int64_t N, int K
     const int64_t nb = (N + batch - 1) / batch;
     const int grid_r = (int)(nb < L.grid ? nb : L.grid);
     size_t lds = (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc * 4 + (size_t)((K + 1) & ~1) * 4 + (size_t)VQ_FAST_ROWS * 12 +
-                 (size_t)2 * batch * 4 + (size_t)nwr * 64 * 4 + 32 * 4;
+                 (size_t)2 * batch * 4 + (size_t)nwr * 64 * 4 + 32 * 4 + (size_t)VQ_PZ_CAP * d * sizeof(T);
     const size_t fold = (size_t)2 * nwr * 64 * sizeof(double);
     if (lds < fold) lds = fold;
     if (lds > 160 * 1024) return frl_fail(-3, "vq_assign: LDS budget exceeded");
