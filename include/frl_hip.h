@@ -123,6 +123,12 @@ int frl_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const f
  * sum of the loss terms (scripts/train_vqvae.py:236-248) and the isfinite guard (step.py:1057-1074) in one launch; its backward. */
 int frl_scalar_combine(const float* const* terms_host, const float* coef_host, int n, float* out, float* ok_out, frl_stream_t stream);
 int frl_scalar_fanout(const float* g, const float* coef_host, int n, float* out, frl_stream_t stream);
+/* the same with optional device multipliers (mult_host: n device pointers, entries or the array may be NULL): term i is weighted by
+ * coef[i] * *mult[i] -- a loss weight on a per-step schedule (lambda_vq(step), scripts/train_vqvae.py:236-248,324) stays a device word
+ * that a captured graph reads at replay time */
+int frl_scalar_combine_dev(const float* const* terms_host, const float* coef_host, const float* const* mult_host, int n, float* out,
+                           float* ok_out, frl_stream_t stream);
+int frl_scalar_fanout_dev(const float* g, const float* coef_host, const float* const* mult_host, int n, float* out, frl_stream_t stream);
 
 /* ---- fused two-layer type encoder (csrc/enc_fused.hip) -----------------------------------------------------------
  * conv1x1 C0->C1 (no bias) -> GroupNorm(G1) -> ReLU -> conv1x1 C1->C2 (no bias) -> GroupNorm(G2): Conv2DEncoder with two layers

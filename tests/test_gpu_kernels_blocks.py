@@ -108,6 +108,44 @@ def test_fused_two_layer_encoder_matches_float64_and_the_modular_path(B, H, W):
     y = F.relu(O.group_norm(F.conv2d(x, ps[convs[0]]), 8, ps[gam[0]], ps[bet[0]]))
     zr = O.group_norm(F.conv2d(y, ps[convs[1]]), 8, ps[gam[1]], ps[bet[1]])
     zr.backward(dz)
+    # The same chain in float64 with bf16 rounding emulated where the kernels round: the hidden activation h (operand of the second
+    # convolution), the gradients of the two convolution outputs (operands of dW = dy^T x and W^T dy) and d h = W2^T dy2.  The modular
+    # kernels additionally STORE the convolution outputs y1, y2 (the GroupNorm inputs) as bf16 tensors; the fused kernels keep them in
+    # float32.  That one rounding matters: the GroupNorm backward removes the projections of the gradient onto 1 and xhat, dW1 is a small
+    # remainder of cancelling sums, and a 2^-9 perturbation of xhat moves it by 3-9 % of max |dW1| (tools/diag/enc_err.py).  So:
+    # the fused path is held tightly to the chain WITHOUT the y1 / y2 rounding (and through it to the exact one), the modular path
+    # tightly to the chain WITH it -- what is left in both cases is accumulation order, not operand precision.
+    class _RoundFwd(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return q(t, torch.bfloat16)
+
+        @staticmethod
+        def backward(ctx, g_):
+            return g_
+
+    class _RoundBwd(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g_):
+            return q(g_, torch.bfloat16)
+
+    def emulated(round_prenorm):
+        pe = {n: ps[n].detach().clone().requires_grad_(True) for n in names}
+        c1 = _RoundBwd.apply(F.conv2d(x, pe[convs[0]]))
+        if round_prenorm:
+            c1 = _RoundFwd.apply(c1)
+        h = _RoundFwd.apply(_RoundBwd.apply(F.relu(O.group_norm(c1, 8, pe[gam[0]], pe[bet[0]]))))
+        c2 = _RoundBwd.apply(F.conv2d(h, pe[convs[1]]))
+        if round_prenorm:
+            c2 = _RoundFwd.apply(c2)
+        O.group_norm(c2, 8, pe[gam[1]], pe[bet[1]]).backward(dz)
+        return {n: pe[n].grad for n in names}
+
+    ref_fused, ref_modular = emulated(False), emulated(True)
     enc = enc.to(DEV).train()
     xd, dzd = nhwc(x).to(torch.bfloat16).to(DEV), nhwc(dz).to(torch.bfloat16).to(DEV)
     out = {}
@@ -122,12 +160,11 @@ def test_fused_two_layer_encoder_matches_float64_and_the_modular_path(B, H, W):
         z, grads = out[fuse]
         assert rel_err(z, nhwc(zr.detach())) <= 3e-2, fuse
         for n in names:
-            if H * W >= 256:                                        # (32-pixel samples: the bf16 rounding of dh, dy1, dy2 dominates the cancelling sums)
-                assert rel_err(grads[n], ps[n].grad) <= 1e-1, (fuse, n)
-    # fused and modular round at the same places: they agree far below the bf16 tolerance
-    assert rel_err(out[True][0], out[False][0].double()) <= 1.6e-2
+            assert rel_err(grads[n], (ref_fused if fuse else ref_modular)[n]) <= 5e-3, (fuse, n)      # every sample size
+    # the fused path against the EXACT float64 chain: only operand rounding of h, dh, dy is left (was 7e-2 with y1 / y2 rounded)
     for n in names:
-        assert rel_err(out[True][1][n], out[False][1][n]) <= 1e-2, n
+        assert rel_err(out[True][1][n], ps[n].grad) <= 1.5e-2, n
+    assert rel_err(out[True][0], out[False][0].double()) <= 1.6e-2
 
 
 @pytest.mark.parametrize("dtype,atol,wtol", MODES)

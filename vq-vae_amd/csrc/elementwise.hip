@@ -205,18 +205,26 @@ static inline unsigned ew_grid(int64_t n) {
   else if ((DTYPE) == FRL_BF16) { if (VECOK(8)) { CALL_BF16V; } else { CALL_BF16S; } } \
   else return frl_fail(-2, "bad dtype");
 
-struct ScalarTerms { const float* p[8]; float c[8]; };
+// m[i] (optional): a device scalar that multiplies coef[i] -- a weight that follows a per-step schedule (lambda_vq(step)) without being
+// baked into a captured graph as a kernel argument
+struct ScalarTerms { const float* p[8]; const float* m[8]; float c[8]; };
 __global__ void scalar_combine_kernel(ScalarTerms t, int n, float* __restrict__ out, float* __restrict__ ok_out) {
   float s = 0.f;
-  for (int i = 0; i < n; ++i) s = fmaf(t.c[i], *t.p[i], s);
+  for (int i = 0; i < n; ++i) s = fmaf(t.m[i] != nullptr ? t.c[i] * *t.m[i] : t.c[i], *t.p[i], s);
   out[0] = s;
   if (ok_out != nullptr) ok_out[0] = (s * 0.f == 0.f) ? 1.f : 0.f;   // x * 0 == 0 holds exactly for finite x
 }
 __global__ void scalar_fanout_kernel(const float* __restrict__ g, ScalarTerms t, int n, float* __restrict__ out) {
-  if ((int)threadIdx.x < n) out[threadIdx.x] = g[0] * t.c[threadIdx.x];
+  if ((int)threadIdx.x < n) {
+    const int i = threadIdx.x;
+    out[i] = g[0] * (t.m[i] != nullptr ? t.c[i] * *t.m[i] : t.c[i]);
+  }
 }
 
 extern "C" {
+int frl_scalar_combine_dev(const float* const* terms_host, const float* coef_host, const float* const* mult_host, int n, float* out, float* ok_out,
+                           hipStream_t stream);
+int frl_scalar_fanout_dev(const float* g, const float* coef_host, const float* const* mult_host, int n, float* out, hipStream_t stream);
 
 size_t frl_mse_workspace_bytes(void) { return (size_t)EW_GRID_MAX * 2 * sizeof(double); }
 
@@ -319,17 +327,34 @@ int frl_add(const void* a, const void* b, float scale_b, void* out, int64_t n, i
 // (the device-side isfinite guard of the trainer: step.py:1057-1074).  Replaces the chain of scalar mul / add / compare kernels that
 // `lambda_recon * L + lambda_vq * (L_cb + beta * L_cm) + ...` costs as separate launches.  n <= 8; coef are host values.
 int frl_scalar_combine(const float* const* terms_host, const float* coef_host, int n, float* out, float* ok_out, hipStream_t stream) {
+  return frl_scalar_combine_dev(terms_host, coef_host, nullptr, n, out, ok_out, stream);
+}
+// The same with optional device multipliers: out[0] = sum_i coef[i] * (mult[i] ? *mult[i] : 1) * *terms[i]  (mult_host: array of n device
+// pointers, entries or the array itself may be NULL).  A weight that changes every step is then a device word, not a kernel argument.
+int frl_scalar_combine_dev(const float* const* terms_host, const float* coef_host, const float* const* mult_host, int n, float* out, float* ok_out,
+                           hipStream_t stream) {
   if (n < 1 || n > 8) return frl_fail(-2, "scalar_combine: 1..8 terms");
   ScalarTerms t;
-  for (int i = 0; i < 8; ++i) { t.p[i] = i < n ? terms_host[i] : nullptr; t.c[i] = i < n ? coef_host[i] : 0.f; }
+  for (int i = 0; i < 8; ++i) {
+    t.p[i] = i < n ? terms_host[i] : nullptr;
+    t.m[i] = (i < n && mult_host != nullptr) ? mult_host[i] : nullptr;
+    t.c[i] = i < n ? coef_host[i] : 0.f;
+  }
   FRL_LAUNCH(scalar_combine_kernel, dim3(1), dim3(1), 0, stream, t, n, out, ok_out);
   return frl_check_launch("scalar_combine");
 }
-// Backward of frl_scalar_combine: out[i] = g[0] * coef[i].
+// Backward of frl_scalar_combine: out[i] = g[0] * coef[i] (* *mult[i]).
 int frl_scalar_fanout(const float* g, const float* coef_host, int n, float* out, hipStream_t stream) {
+  return frl_scalar_fanout_dev(g, coef_host, nullptr, n, out, stream);
+}
+int frl_scalar_fanout_dev(const float* g, const float* coef_host, const float* const* mult_host, int n, float* out, hipStream_t stream) {
   if (n < 1 || n > 8) return frl_fail(-2, "scalar_fanout: 1..8 terms");
   ScalarTerms t;
-  for (int i = 0; i < 8; ++i) { t.p[i] = nullptr; t.c[i] = i < n ? coef_host[i] : 0.f; }
+  for (int i = 0; i < 8; ++i) {
+    t.p[i] = nullptr;
+    t.m[i] = (i < n && mult_host != nullptr) ? mult_host[i] : nullptr;
+    t.c[i] = i < n ? coef_host[i] : 0.f;
+  }
   FRL_LAUNCH(scalar_fanout_kernel, dim3(1), dim3(8), 0, stream, g, t, n, out);
   return frl_check_launch("scalar_fanout");
 }

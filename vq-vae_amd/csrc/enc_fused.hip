@@ -11,7 +11,8 @@
 //             pass 2: dy2 = GN2'(dz), dh = W2^T dy2; per-channel sums for GN1         -> dy2, h, dh to HBM (operands of the two
 //                     weight-gradient GEMMs, which stay with pw_wgrad_kernel), d beta1, d gamma1, group terms of GN1
 //             pass 3: dy1 = GN1'(relu'(dh))                                            -> dy1 (overwrites dh)
-// Intermediates are rounded to bf16 exactly where the modular path stores them (y1, h, y2, dh), and the normalisation uses the
+// Intermediates are rounded to bf16 where the modular path stores them and a matrix-core operand needs bf16 anyway (h, dh, dy1, dy2); the
+// GroupNorm inputs y1, y2 stay float32 (see ef_keep), and the normalisation uses the
 // modular kernels' formulas (norm.hip: y = fma(x, rstd*gamma, beta - mean*rstd*gamma); dx = fma(A, d, fma(E, x, F))).
 // Every wave keeps 16-pixel tiles in the lane-quarter register image (frl_common.hpp): the output of one contraction IS the B operand
 // of the next.  Weights: packed MFMA fragment images in LDS (48 KB); the sample's rows are re-read per pass (L2 / Infinity Cache).
@@ -45,6 +46,12 @@ __device__ __forceinline__ float ef_row_sum(float v) {
   return v;
 }
 __device__ __forceinline__ float ef_r(float v) { return (float)(bf16)v; }     // the bf16 rounding of a tensor the modular path stores
+// The two convolution outputs (the GroupNorm inputs y1, y2) are NOT rounded here, although the modular path stores them as bf16: nothing of
+// them is ever stored by this kernel, and their rounding is what the encoder's weight gradients are most sensitive to -- the GroupNorm
+// backward removes the projections of the gradient onto 1 and xhat, so dW = dy^T x is a small remainder of cancelling sums, and a 2^-9
+// perturbation of xhat leaks 3-9 % of max |dW1| back in (tools/diag/enc_err.py: with y1 / y2 rounded the result equals the float64 chain
+// with the same two roundings to 2e-4, and is 3.4 % / 9.4 % away from the exact chain at 32x32 / 4x8 samples).
+__device__ __forceinline__ float ef_keep(float v) { return v; }
 
 // y1 (rounded) of one tile: 32 channels of the lane's pixel (channel 32 kc + j)
 __device__ __forceinline__ void ef_conv1(float (&y1)[32], const LQTile<TT, 2>& xt, const frag8* __restrict__ w1, int lane) {
@@ -54,7 +61,7 @@ __device__ __forceinline__ void ef_conv1(float (&y1)[32], const LQTile<TT, 2>& x
 #pragma unroll
     for (int s = 0; s < 2; ++s) a = mfma16(w1[(m * 2 + s) * 64 + lane], xt.f[s], a);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) y1[4 * m + r] = ef_r(a[r]);
+    for (int r = 0; r < 4; ++r) y1[4 * m + r] = ef_keep(a[r]);
   }
 }
 // h = relu(fma(y1, A1, O1)) as the B operand of the second contraction; y2 (rounded): 16 channels of the pixel (channel 16 kc + j)
@@ -79,7 +86,7 @@ __device__ __forceinline__ void ef_conv2(float (&y2)[16], const LQTile<TT, 4>& h
 #pragma unroll
     for (int s = 0; s < 4; ++s) a = mfma16(w2[(m * 4 + s) * 64 + lane], ht.f[s], a);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) y2[4 * m + r] = ef_r(a[r]);
+    for (int r = 0; r < 4; ++r) y2[4 * m + r] = ef_keep(a[r]);
   }
 }
 
@@ -91,7 +98,7 @@ __device__ __forceinline__ void ef_conv1r(float (&y1)[32], const LQTile<TT, 2>& 
 #pragma unroll
     for (int s = 0; s < 2; ++s) a = mfma16(w1r[m * 2 + s], xt.f[s], a);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) y1[4 * m + r] = ef_r(a[r]);
+    for (int r = 0; r < 4; ++r) y1[4 * m + r] = ef_keep(a[r]);
   }
 }
 __device__ __forceinline__ void ef_conv2r(float (&y2)[16], const LQTile<TT, 4>& ht, const frag8 (&w2r)[16]) {
@@ -101,7 +108,7 @@ __device__ __forceinline__ void ef_conv2r(float (&y2)[16], const LQTile<TT, 4>& 
 #pragma unroll
     for (int s = 0; s < 4; ++s) a = mfma16(w2r[m * 4 + s], ht.f[s], a);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) y2[4 * m + r] = ef_r(a[r]);
+    for (int r = 0; r < 4; ++r) y2[4 * m + r] = ef_keep(a[r]);
   }
 }
 

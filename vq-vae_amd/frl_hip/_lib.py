@@ -59,6 +59,8 @@ SIGNATURES = {
     "frl_groupnorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P, S, P]),
     "frl_scalar_combine": (c_int, [P, P, I, P, P, P]),
     "frl_scalar_fanout": (c_int, [P, P, I, P, P]),
+    "frl_scalar_combine_dev": (c_int, [P, P, P, I, P, P, P]),
+    "frl_scalar_fanout_dev": (c_int, [P, P, P, I, P, P]),
     "frl_encoder2_supported": (c_int, [I, I, I, I, I, I, I]),
     "frl_encoder2_workspace_bytes": (S, [I]),
     "frl_encoder2_fwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, F, P, S, P]),

@@ -102,29 +102,33 @@ class ScalarCombineFn(Function):
     """sum_i coef_i * term_i over device scalars in one launch (plus its finite flag); backward: one launch for all term gradients."""
 
     @staticmethod
-    def forward(ctx, coefs, *terms):
-        loss, ok = ops.scalar_combine([t.detach() for t in terms], coefs)
+    def forward(ctx, coefs, mults, *terms):
+        loss, ok = ops.scalar_combine([t.detach() for t in terms], coefs, mults)
         ctx.coefs = tuple(float(c) for c in coefs)
+        ctx.mults = mults                                           # device scalars (no gradient: schedule values), read again in the backward
         ctx.mark_non_differentiable(ok)
         return loss, ok
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g, g_ok):
-        gg = ops.scalar_fanout(g.reshape(1).float().contiguous(), ctx.coefs)
-        return (None,) + tuple(gg[i] for i in range(len(ctx.coefs)))
+        gg = ops.scalar_fanout(g.reshape(1).float().contiguous(), ctx.coefs, ctx.mults)
+        return (None, None) + tuple(gg[i] for i in range(len(ctx.coefs)))
 
 
-def scalar_combine(terms, coefs):
-    """-> (sum_i coef_i * term_i [0-dim], ok [1] = 1.0 if finite else 0.0 | None); plain torch arithmetic off the GPU path."""
+def scalar_combine(terms, coefs, mults=None):
+    """-> (sum_i coef_i * mult_i * term_i [0-dim], ok [1] = 1.0 if finite else 0.0 | None); plain torch arithmetic off the GPU path.
+    mults: optional device float scalars (or None entries) that scale a term's weight at run time (a scheduled loss weight)."""
     fits = all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.numel() == 1 for t in terms) and 1 <= len(terms) <= 8
     if not fits:
         tot = None
-        for t, c in zip(terms, coefs):
+        for i, (t, c) in enumerate(zip(terms, coefs)):
             v = t if c == 1.0 else c * t
+            if mults is not None and mults[i] is not None:
+                v = v * mults[i].reshape(()).to(v.device)
             tot = v if tot is None else tot + v
         return tot, None
-    return ScalarCombineFn.apply(tuple(coefs), *[t.reshape(()) for t in terms])
+    return ScalarCombineFn.apply(tuple(coefs), None if mults is None else tuple(mults), *[t.reshape(()) for t in terms])
 
 
 class SobelFn(Function):

@@ -137,6 +137,9 @@ class VQVAE(RepresentationModel):
             self.decoder_phase = Conv2DHead(self.z_phase_dim, [hidden], in_features)
             if phase_codebook_size:
                 self.quant_phase = VectorQuantizer(phase_codebook_size, self.z_phase_dim, beta, quantizer, ema_decay, ema_eps)
+        # a trainer with a per-step lambda_vq(step) schedule keeps the current value in this device scalar (float32 [1]); the loss head then
+        # reads it at run time, so a captured step follows the schedule (None: the host value self.lambda_vq is baked into the launch)
+        self.lambda_vq_dev: Optional[torch.Tensor] = None
         self.codebook_manager = None
         self._manager_takes_rows = False
         self.defer_codebook_hooks = False                   # set by a trainer with an isfinite guard: see commit_codebook_hooks
@@ -182,7 +185,7 @@ class VQVAE(RepresentationModel):
         if hasattr(self, "quant_phase"):
             zpq, pvq, pperp, pidx = self.quant_phase(z_phase.reshape(-1, z_phase.shape[-1]))
             zp_in = zpq.reshape(z_phase.shape)
-            terms.append((pvq, self.lambda_vq))
+            terms.append(self._vq_term(pvq))
             out.update(idx_phase=pidx, vq_loss_phase=pvq, perplexity_phase=pperp)
         if mask is None or mask.dim() == 4:                                 # [B,T,H,W]: per-observation validity from the tile ingest
             pmask = mask
@@ -225,7 +228,7 @@ class VQVAE(RepresentationModel):
         out = dict(z_type=z_type, gate=gate, idx=idx, vq_loss=vq_loss, perplexity=perp, l_type=l_type, vq_stats=self.quant.last_stats)
         if xhat_type is not None:
             out["xhat_type"] = xhat_type
-        terms = [(l_type, self.lambda_recon), (vq_loss, self.lambda_vq)]
+        terms = [(l_type, self.lambda_recon), self._vq_term(vq_loss)]
         if self.phase:
             if side is not None:
                 main.wait_stream(side)
@@ -237,7 +240,7 @@ class VQVAE(RepresentationModel):
             terms += ph.pop("loss_terms")
             out.update(ph)
         # weighted sum of the loss terms and its isfinite flag in ONE launch (the trainer's device-side guard reads out["loss_ok"])
-        loss, ok = Fh.scalar_combine([t for t, _ in terms], [float(w) for _, w in terms])
+        loss, ok = Fh.scalar_combine([t[0] for t in terms], [float(t[1]) for t in terms], [t[2] if len(t) > 2 else None for t in terms])
         out["loss"] = loss
         if ok is not None:
             out["loss_ok"] = ok
@@ -277,6 +280,12 @@ class VQVAE(RepresentationModel):
                 draw(self.forward_phase_nhwc(tile, z_type), self.quant_phase)
         finally:
             self.train(was_training)
+
+    def _vq_term(self, vq_loss):
+        """(term, host weight[, device multiplier]) of a quantizer loss in the total: lambda_vq from the device scalar when a trainer set one"""
+        if self.lambda_vq_dev is not None and vq_loss.is_cuda:
+            return (vq_loss, 1.0, self.lambda_vq_dev)
+        return (vq_loss, self.lambda_vq)
 
     def _quantizers(self):
         return [q for q in (getattr(self, "quant", None), getattr(self, "quant_phase", None)) if q is not None]

@@ -328,8 +328,18 @@ def vq_ema_update(sums, counts, ema_count, ema_sum, codebook, decay: float, eps:
 # ----------------------------------------------------------------------------------------------
 # GroupNorm over NHWC rows (csrc/norm.hip)
 # ----------------------------------------------------------------------------------------------
-def scalar_combine(terms, coefs):
-    """[device float scalars], [host floats] -> (value [] f32 = sum coef_i * term_i, ok [1] f32 = 1.0 if the value is finite else 0.0)."""
+def _mult_ptrs(mults, n):
+    if mults is None or all(m is None for m in mults):
+        return None
+    for m in mults:
+        if m is not None and (m.dtype != torch.float32 or m.numel() != 1 or not m.is_cuda):
+            raise ValueError("scalar_combine: multipliers are float32 CUDA scalars")
+    return (ctypes.c_void_p * n)(*[0 if m is None else m.data_ptr() for m in mults])
+
+
+def scalar_combine(terms, coefs, mults=None):
+    """[device float scalars], [host floats](, [device float scalars | None]) -> (value [] f32 = sum coef_i * mult_i * term_i, ok [1] f32 = 1.0 if
+    the value is finite else 0.0).  A multiplier is read on the device at run time (a scheduled loss weight inside a captured graph)."""
     n = len(terms)
     dev = terms[0].device
     for t in terms:
@@ -339,16 +349,16 @@ def scalar_combine(terms, coefs):
     cf = (ctypes.c_float * n)(*[float(c) for c in coefs])
     out = torch.empty((), dtype=torch.float32, device=dev)
     ok = torch.empty(1, dtype=torch.float32, device=dev)
-    check(_lib.load().frl_scalar_combine(ptrs, cf, n, _p(out), _p(ok), _stream()), "frl_scalar_combine")
+    check(_lib.load().frl_scalar_combine_dev(ptrs, cf, _mult_ptrs(mults, n), n, _p(out), _p(ok), _stream()), "frl_scalar_combine")
     return out, ok
 
 
-def scalar_fanout(g, coefs):
-    """g device float scalar -> out [n] f32 with out[i] = g * coef_i."""
+def scalar_fanout(g, coefs, mults=None):
+    """g device float scalar -> out [n] f32 with out[i] = g * coef_i (* mult_i)."""
     n = len(coefs)
     cf = (ctypes.c_float * n)(*[float(c) for c in coefs])
     out = torch.empty(n, dtype=torch.float32, device=g.device)
-    check(_lib.load().frl_scalar_fanout(_p(g), cf, n, _p(out), _stream()), "frl_scalar_fanout")
+    check(_lib.load().frl_scalar_fanout_dev(_p(g), cf, _mult_ptrs(mults, n), n, _p(out), _stream()), "frl_scalar_fanout")
     return out
 
 

@@ -47,6 +47,7 @@ class BucketedGradAllReduce:
         self._tables: Dict[int, tuple] = {}                 # bucket -> (gradient pointer key, device desc table, device chunk table)
         self.on_gpu = bool(self.buckets) and self.buckets[0][0].is_cuda
         self._train_stream = None
+        self._collective_always = bool(force_hooks and dist.is_available() and dist.is_initialized())
         if self.world > 1 or force_hooks:
             for bucket in self.buckets:
                 for p in bucket:
@@ -95,7 +96,8 @@ class BucketedGradAllReduce:
                 if bi == len(self.buckets) - 1:
                     flat[off] = self.flag_src.reshape(()) if self.flag_src is not None else 0.0
                 flat.div_(self.world)
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if self.world > 1 else None
+            # (a single-rank group still issues the collective when one exists: the RCCL call is then part of what a captured step records)
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if (self.world > 1 or self._collective_always) else None
         self._works.append((bi, work))
 
     def _pack_gpu(self, bi: int):

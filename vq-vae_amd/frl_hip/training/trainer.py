@@ -47,6 +47,9 @@ class VQVAETrainer:
         self.check_finite = check_finite
         self.beta_schedule_cfg = beta_schedule_cfg
         self.lambda_vq_schedule = lambda_vq_schedule           # lambda_vq(step) of scripts/train_vqvae.py:236-248,324 (None: constant)
+        if lambda_vq_schedule is not None and self.hip_opt and hasattr(model, "lambda_vq_dev"):
+            # the scheduled weight lives in a device scalar the loss head reads at run time: a captured step follows the schedule
+            model.lambda_vq_dev = torch.full((1,), float(lambda_vq_schedule(0)), dtype=torch.float32, device=rest[0].device)
         self.step_idx = 0
         self.epoch = 0
         self.skipped = 0
@@ -98,12 +101,30 @@ class VQVAETrainer:
     # when they change; a lambda_vq(step) schedule that changes every step keeps the eager path.
     # ------------------------------------------------------------------------------------------------------------------
     def graph_supported(self) -> bool:
-        return bool(self.hip_opt and self.check_finite and self.lambda_vq_schedule is None and self.reducer is None)
+        """The step can be captured: device-side optimizer and isfinite guard; a lambda_vq(step) schedule needs the model's device scalar;
+        data parallel needs gradients on the GPU (RCCL collectives are captured with the step, gloo ones cannot be)."""
+        if not (self.hip_opt and self.check_finite):
+            return False
+        if self.lambda_vq_schedule is not None and getattr(self.model, "lambda_vq_dev", None) is None:
+            return False
+        if self.reducer is not None and self.reducer.active:
+            return bool(self.reducer.on_gpu and (self.reducer.world == 1 or dist.get_backend(self.reducer.group) == "nccl"))
+        return True
+
+    def _set_lambda_vq(self) -> None:
+        """loss = lambda_recon L + lambda_vq(step) (L_codebook + beta L_commit): host attribute (reports, eager CPU paths) and device scalar"""
+        if self.lambda_vq_schedule is None:
+            return
+        v = float(self.lambda_vq_schedule(self.step_idx))
+        self.model.lambda_vq = v
+        if getattr(self.model, "lambda_vq_dev", None) is not None:
+            self.model.lambda_vq_dev.fill_(v)
 
     def _graph_key(self, tile, mask):
         q = getattr(self.model, "quant", None)
+        lam = None if getattr(self.model, "lambda_vq_dev", None) is not None else getattr(self.model, "lambda_vq", None)   # (device scalar: not baked)
         return (tuple(tile.shape), tile.dtype, None if mask is None else (tuple(mask.shape), mask.dtype),
-                getattr(q, "beta", None), getattr(self.model, "lambda_vq", None), getattr(self.model, "lambda_recon", None),
+                getattr(q, "beta", None), lam, getattr(self.model, "lambda_recon", None),
                 getattr(self.model, "concurrent_phase", None), self.max_norm)
 
     def step_graphed(self, tile: torch.Tensor, mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
@@ -114,6 +135,7 @@ class VQVAETrainer:
         # A graph reads its input at a fixed address.  Inputs that come from a small ring of device buffers (TilePrefetcher slots,
         # the benchmark's tile pool) get one graph per buffer -- all of them share one memory pool, they never run concurrently --
         # so that no copy into a staging tensor is needed; beyond MAX_GRAPHS distinct buffers the input is copied into a staging tile of the trainer's own.
+        self._set_lambda_vq()
         key = self._graph_key(tile, mask)
         graphs = self.__dict__.setdefault("_graphs", {})
         if graphs and next(iter(graphs.values()))["key"] != key:
@@ -272,18 +294,31 @@ class VQVAETrainer:
         schedule, no host sync): the part of `step` that a graph can hold."""
         self.model.train()
         self.opt.zero_grad(set_to_none=True)
+        dp = self.reducer is not None and self.reducer.active
+        if dp:
+            self.reducer.reset()                                   # (hooks count down per step; the training stream is the capturing one)
+
+        def fwd_bwd():
+            out_ = self.model.forward_tiles(tile, mask)
+            ok_ = self._finite_flag(out_)
+            if dp:
+                self.reducer.flag_src = 1.0 - ok_                  # rides in the last gradient bucket: every rank takes the same decision
+            out_["loss"].backward()                                # data parallel: the bucket hooks pack + all-reduce on the side stream
+            return out_, ok_
+
         if self.pack_cache is not None:
             with self.pack_cache:
-                out = self.model.forward_tiles(tile, mask)
-                loss = out["loss"]
-                ok = self._finite_flag(out)
-                loss.backward()
+                out, ok = fwd_bwd()
         else:
-            out = self.model.forward_tiles(tile, mask)
-            loss = out["loss"]
-            ok = self._finite_flag(out)
-            loss.backward()
-        out["grad_norm"] = self.opt.step(self.max_norm, None, ok)
+            out, ok = fwd_bwd()
+        grads = None
+        if dp:
+            # the collectives (RCCL) and the stream joins are part of the capture; the optimizer reads the averaged gradients in place
+            self.reducer.finish(scatter=False)
+            fg = self.reducer.flat_grads()
+            grads = [fg[id(p)] if p.grad is not None else None for p in self.opt.params]
+            ok = (self.reducer.flag_result() == 0).float()         # 1 <=> no rank reported a non-finite loss
+        out["grad_norm"] = self.opt.step(self.max_norm, grads, ok)
         self._images_refresh()
         if getattr(self.model, "defer_codebook_hooks", False):
             self.model.commit_codebook_hooks(ok)
@@ -299,8 +334,7 @@ class VQVAETrainer:
             g["lr"] = lr_now
         if self.opt_lr_dev_sync():
             pass
-        if self.lambda_vq_schedule is not None:                # loss = lambda_recon L + lambda_vq(step) (L_codebook + beta L_commit)
-            self.model.lambda_vq = self.lambda_vq_schedule(self.step_idx)
+        self._set_lambda_vq()
         self.model.train()
         self.opt.zero_grad(set_to_none=True)
         self._images_current()
