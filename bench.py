@@ -304,7 +304,7 @@ def main():
             out["vq_hbm"]["assign_kernel_rocprof"] = {"us": ku[0], "GB/s": round(vq_bytes / ku[0] / 1e3, 1),
                                                       "frac": round(vq_bytes / ku[0] / 1e3 / HBM_PEAK_GBS, 4), "source": ku[1]}
         # --- conv MFMA: algorithmic dense FLOPs of the step (3 x forward) over the event time of every conv / TCN op
-        conv_keys = [k for k in ksum if k.startswith(("conv", "tcn")) and k != "tcn_block_bwd.main"]
+        conv_keys = [k for k in ksum if k.startswith(("conv", "tcn", "film_fused", "smooth_heads", "decoder_mse", "encoder2")) and k != "tcn_block_bwd.main"]
         conv_ms = sum(ksum[k][1] for k in conv_keys) / args.steps
         flops = 3 * conv_flops_per_tile(args.time, args.size, args.features, args.emb_dim, model.z_phase_dim) * args.batch
         out["conv_mfma"] = {"TFLOP/s": round(flops / conv_ms / 1e9, 1), "frac": round(flops / conv_ms / 1e9 / MFMA_BF16_PEAK_TF, 4),
@@ -312,7 +312,7 @@ def main():
                             "note": "algorithmic 3x-forward dense FLOPs / HIP-event time of all conv + TCN ops (C-ABI call spans: "
                                     "slab reductions and launch gaps of each call included)"}
         # the same FLOPs over the contraction kernels alone (library-side event pairs around each launch)
-        mm = ("tcn_hot", "pw_conv", "pw_wgrad", "conv3x3", "dec_mse_fwd", "dec_mse_bwd")
+        mm = ("tcn_hot", "tcn_chain", "pw_conv", "pw_wgrad", "conv3x3", "dec_mse_fwd", "dec_mse_bwd", "enc2_", "film_fused", "smooth_heads")
         mm_ms = sum(ms for k, (_, ms) in kern.items() if any(t in k for t in mm)) / args.steps
         if mm_ms > 0:
             out["conv_mfma"]["kernels_only"] = {"TFLOP/s": round(flops / mm_ms / 1e9, 1), "ms_per_step": round(mm_ms, 3),
@@ -323,8 +323,10 @@ def main():
         # --- dominant kernel -> headline roofline object
         # dominant kernel FAMILY among those with a per-launch work model below (the fused TCN kernels at the measured configuration)
         # (kernel families with a per-launch work model; time = the library-side event pairs around the kernel launches themselves)
-        fam = {"tcn_block_bwd.main": "tcn_hot_bwd", "tcn_block_fwd": "tcn_hot_fwd", "vq_assign": "vq_assign_kernel",
-               "edge_smooth_fwd": "smooth_fwd", "edge_smooth_bwd": "smooth_bwd"}
+        fam = {"tcn_block_bwd.main": "tcn_hot_bwd3_kernel", "tcn_block_bwd.nodx": "tcn_hot_bwd3_nodx_kernel", "tcn_block_fwd": "tcn_hot_fwd",
+               "tcn_chain_fwd": "tcn_chain_fwd_kernel", "vq_assign": "vq_assign_kernel", "edge_smooth_fwd": "smooth_fwd_bf16",
+               "edge_smooth_bwd": "smooth_bwd_bf16", "smooth_heads_fwd": "smooth_heads_fwd_kernel", "smooth_heads_bwd": "smooth_heads_bwd_kernel",
+               "smooth_dx": "smooth_dx"}
         ftime = {}
         for name, sub in fam.items():
             hit = [v for k, v in kern.items() if sub in k]
@@ -382,8 +384,10 @@ def profiled_kernel_us(substr):
 
 def pmc_traffic(name):
     """HBM bytes per launch from the newest committed rocprofv3 --pmc passes (profiles/*_pmc.json), or None."""
-    key = {"tcn_block_bwd.main": "tcn_hot_bwd", "tcn_block_fwd": "tcn_hot_fwd_kernel", "vq_assign": "vq_assign_kernel",
-           "edge_smooth_bwd": "smooth_bwd_bf16r4_kernel", "conv1x1_bwd_weight": "pw_wgrad_kernel"}.get(name)
+    key = {"tcn_block_bwd.main": "tcn_hot_bwd3_kernel<", "tcn_block_bwd.nodx": "tcn_hot_bwd3_kernel<", "tcn_block_fwd": "tcn_hot_fwd_kernel",
+           "tcn_chain_fwd": "tcn_chain_fwd_kernel", "vq_assign": "vq_assign", "edge_smooth_bwd": "smooth_bwd_bf16r4_kernel",
+           "smooth_heads_fwd": "smooth_heads_fwd_kernel", "smooth_heads_bwd": "smooth_heads_bwd_kernel", "smooth_dx": "smooth_dx",
+           "conv1x1_bwd_weight": "pw_wgrad_kernel"}.get(name)
     try:
         import glob
         f = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))[-1]
@@ -404,13 +408,20 @@ def roofline_for(name, ksum, args, model, n, s):
     avg = ms / calls
     T, d = args.time, args.emb_dim
     base = {"kernel": name, "traffic": pmc_traffic(name), "avg_ms": round(avg, 4), "launches_per_step": calls / args.steps}
-    if name.startswith("tcn_block"):
+    if name.startswith("tcn_"):
         rows = n * T
         # valid temporal taps averaged over the three dilations (1, 2, 4) at this T
         taps = sum(sum(1 for t in range(T) for k in (-1, 0, 1) if 0 <= t + k * dl < T) for dl in (1, 2, 4)) / (3.0 * T)
         if name == "tcn_block_fwd":
             flops = rows * 2 * 64 * 64 * (taps + 1)                 # conv + gate GEMM
             nbytes = rows * 64 * s * 2                              # x read, y written
+        elif name == "tcn_chain_fwd":                               # three blocks + the 1x1 head in one launch
+            zp = model.z_phase_dim
+            flops = rows * (3 * 2 * 64 * 64 * (taps + 1) + 2 * 64 * zp)
+            nbytes = rows * s * (64 * 4 + zp)                       # x read; y1, y2, y3 and the head output written
+        elif name == "tcn_block_bwd.nodx":                          # the block whose input is the tile itself: no conv^T, no dx
+            flops = rows * 2 * 64 * 64 * (2 * taps + 3)
+            nbytes = rows * 64 * s * 2
         else:
             flops = rows * 2 * 64 * 64 * (3 * taps + 3)             # conv recompute, gate, gate^T, conv^T, two weight-gradient GEMMs
             nbytes = rows * 64 * s * 3                              # x, dy read; dx written
@@ -429,6 +440,15 @@ def roofline_for(name, ksum, args, model, n, s):
         return base
     if name == "vq_assign":
         b = n * (2 * d * s + 4) + args.codebook * d * 4
+        base.update({"bound": "hbm", "achieved": round(b / avg / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(b / avg / 1e6 / HBM_PEAK_GBS, 4), "bytes_per_launch": b})
+        return base
+    if name in ("smooth_heads_fwd", "smooth_heads_bwd", "smooth_dx"):
+        c = args.features
+        per_px = {"smooth_heads_fwd": 4 * c,                        # x, feat read; smoothed, residual written
+                  "smooth_heads_bwd": 4 * c + 4 * c + 32,           # ds, x, feat read, dfeat written; u [4C] and soft-maxed A [32] written
+                  "smooth_dx": 4 * c + 32 + 3 * c}[name]           # u, A read; ds, dx_add read, dx written
+        b = n * s * per_px
         base.update({"bound": "hbm", "achieved": round(b / avg / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(b / avg / 1e6 / HBM_PEAK_GBS, 4), "bytes_per_launch": b})
         return base

@@ -1,15 +1,17 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): GPU parity tests, the bench line, a rocprofv3 kernel-trace summary and the two PMC passes.
-# usage: tools/gpu_round.sh <tag> [quick]     outputs under gpurun_out/<tag>/
+# usage: tools/gpu_round.sh <tag> [quick|notests]     outputs under gpurun_out/<tag>/
 set -o pipefail
 tag=${1:-run}; quick=${2:-}
 out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -x -q > $out/tests.log 2>&1 || { tail -30 $out/tests.log; exit 1; }
-tail -2 $out/tests.log
+if [ "$quick" != notests ]; then
+  python -m pytest tests -m gpu -x -q > $out/tests.log 2>&1 || { tail -30 $out/tests.log; exit 1; }
+  tail -2 $out/tests.log
+fi
 python bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err || { tail -20 $out/bench.err; exit 1; }
 cat $out/bench.json
-[ -n "$quick" ] && exit 0
+[ "$quick" = quick ] && exit 0
 # profiled runs: eager launches (--graph off: one dispatch per kernel on the training streams) with the phase branch on the main stream
 P="--no-cpu-baseline --serial-streams --graph off"
 rocprofv3 --kernel-trace --stats -d $out/prof -o run -- python3 bench.py --steps 20 --warmup 5 $P > $out/prof.log 2>&1 || { tail -20 $out/prof.log; exit 1; }
