@@ -251,6 +251,10 @@ int frl_tcn_chain_fwd(const void* x, const float* const* conv_w, const float* co
  * LDS-DMA, next tile prefetched) and the 8-wave kernel that also takes a mask and ragged pixel counts.  Test hook: on != 0 routes
  * every call through the latter so that the two can be compared on the same inputs. */
 int frl_tcn_hot_force_generic_tiles(int on);   /* returns the previous setting */
+/* Which kernel serves the unmasked, HW % 64 == 0 backward: 4 (default) = tcn_hot_bwd4_kernel (two independent 4-wave subgroups per
+ * workgroup over 32-pixel tiles), 3 = tcn_hot_bwd3_kernel (8 waves in lockstep over 64-pixel tiles).  Same results up to the rounding
+ * of dres (bf16); returns the previous setting.  For A/B measurements and the parity tests of both kernels. */
+int frl_tcn_hot_bwd_variant(int v);
 
 /* ---- optimizer step (frl/training/representation/step.py:1081-1087: clip_grad_norm_(1.0) then AdamW.step()) ---------------
  * Two launches for the whole parameter set.  desc: HOST table of ntensors records {float* p; const float* g; float* m; float* v;

@@ -436,15 +436,26 @@ def test_tcn_hot_kernels_match_oracle_and_generic(B, HW, dil):
         assert rel_err(hot[kk].reshape(ref.shape), gen[kk].reshape(ref.shape).cpu()) <= 2e-2, kk
 
 
-@pytest.mark.parametrize("B,HW,dil", [(21, 1024, 1), (18, 1024, 2), (5, 4096, 4), (600, 64, 1)])
-def test_tcn_hot_bwd_staged_tiles_match_the_8_wave_kernel(B, HW, dil):
-    """frl_tcn_hot_bwd has two kernels (include/frl_hip.h): the LDS-staged one (no mask, HW % 64 == 0) must agree with the 8-wave kernel
-    on the same inputs to bf16 rounding of dx and to float32 summation order of the parameter gradients -- with MORE 64-pixel tiles
-    than workgroups (256), so that every workgroup walks several tiles (next-tile LDS-DMA, X / N buffer swap) -- and twice in a row
-    bit for bit (fixed-order reductions)."""
+@pytest.mark.parametrize("variant", [4, 3])
+@pytest.mark.parametrize("B,HW,dil", [(21, 1024, 1), (18, 1024, 2), (5, 4096, 4), (600, 64, 1), (3, 64, 2)])
+def test_tcn_hot_bwd_staged_tiles_match_the_8_wave_kernel(B, HW, dil, variant):
+    """frl_tcn_hot_bwd has three kernels (include/frl_hip.h): the LDS-staged ones (no mask, HW % 64 == 0; variant 4 = two independent
+    4-wave subgroups per workgroup over 32-pixel tiles, variant 3 = 8 waves in lockstep over 64-pixel tiles) must agree with the round-1
+    8-wave kernel on the same inputs to bf16 rounding of dx and to float32 summation order of the parameter gradients -- with MORE tiles
+    than workgroups (256), so that every workgroup / subgroup walks several tiles (next-tile LDS-DMA, X / N buffer swap), an uneven
+    number of tiles per subgroup, and a launch of three workgroups -- and twice in a row bit for bit (fixed-order reductions)."""
+    from frl_hip import ops, _lib
+    was = _lib.load().frl_tcn_hot_bwd_variant(variant)
+    try:
+        _staged_tiles_case(B, HW, dil)
+    finally:
+        _lib.load().frl_tcn_hot_bwd_variant(was)
+
+
+def _staged_tiles_case(B, HW, dil):
     from frl_hip import ops, _lib
     dtype, cin, cout, G, T = torch.bfloat16, 64, 64, 8, 5
-    assert B * HW // 64 > 256
+    assert B * HW // 64 > 256 or B * HW // 64 == 3
     g = torch.Generator().manual_seed(B * HW + dil)
     w = dict(conv_w=torch.randn(cout, cin, 3, generator=g) / (3 * cin) ** 0.5, conv_b=torch.randn(cout, generator=g) * 0.1,
              gn_w=torch.rand(cout, generator=g) + 0.5, gn_b=torch.randn(cout, generator=g) * 0.2,
@@ -462,7 +473,11 @@ def test_tcn_hot_bwd_staged_tiles_match_the_8_wave_kernel(B, HW, dil):
         lib.frl_tcn_hot_force_generic_tiles(0)
     for k in new:
         assert torch.equal(new[k], again[k]), k
-    assert rel_err(new["dx"].float().cpu(), old["dx"].float().cpu()) <= 6e-3        # both round dx (and dres inside) to bf16
+    # both round dx to bf16; variant 3 and the round-1 kernel also round the same dres = dy - dy g inside, variant 4 keeps dy g (rounded) and
+    # subtracts late, so a quarter of its dx elements land on the neighbouring bf16 value: one ulp = 2^-7 of the element at worst
+    d = (new["dx"].float() - old["dx"].float()).abs().cpu()
+    assert d.max().item() <= 8e-3 * old["dx"].float().abs().max().item()
+    assert d.mean().item() <= 2e-3 * old["dx"].float().abs().mean().item()
     for k in ("conv_w", "conv_b", "gn_w", "gn_b", "gate_w", "gate_b"):
         assert rel_err(new[k].cpu(), old[k].cpu()) <= 2e-3, k
 

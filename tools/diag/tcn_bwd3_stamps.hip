@@ -3,6 +3,7 @@
 // build variants (tools/diag/build.sh): default (timing only), -DB3_STAMPS (phase stamps of tcn_hot_bwd3_kernel)
 #include "../../vq-vae_amd/csrc/tcn_hot.hip"
 #include "../../vq-vae_amd/csrc/tcn_hot_bwd3.hip"
+#include "../../vq-vae_amd/csrc/tcn_hot_bwd4.hip"
 #include "../../vq-vae_amd/csrc/frl_host.hip"
 #include <vector>
 #include <algorithm>
@@ -13,6 +14,7 @@
 int main(int argc, char** argv) {
   const int B = 256, T = 5, HW = 1024, C = 64;
   const int dil = argc > 1 ? atoi(argv[1]) : 1;
+  if (argc > 2) frl_tcn_hot_bwd_variant(atoi(argv[2]));            // 3: tcn_hot_bwd3_kernel, 4 (default): tcn_hot_bwd4_kernel
   const int64_t npix = (int64_t)B * HW, n = npix * T * C;
   std::mt19937 rng(1);
   std::normal_distribution<float> nd(0.f, 1.f);
@@ -44,6 +46,14 @@ int main(int argc, char** argv) {
 #ifdef B3_STAMPS
   CK(hipMemcpyToSymbol(HIP_SYMBOL(b3_dbg), &dbg, sizeof(dbg)));
 #endif
+#ifdef B4_STAMPS
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(b4_dbg), &dbg, sizeof(dbg)));
+  {
+    int knob[2] = {argc > 3 ? atoi(argv[3]) : 0, argc > 4 ? atoi(argv[4]) : 16};
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(b4_knob), knob, sizeof(knob)));
+    printf("knobs: priority mode %d, subgroup 0 share %d/32\n", knob[0], knob[1]);
+  }
+#endif
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int it = 0; it < 5; ++it) {
     CK(hipEventRecord(e0, 0));
@@ -52,11 +62,11 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("iter %d rc=%d  %.1f us (pack + bwd + slab reduce)\n", it, rc, ms * 1e3f);
   }
-#ifndef B3_STAMPS
+#if !defined(B3_STAMPS) && !defined(B4_STAMPS)
   return 0;
 #endif
   {
-    std::vector<unsigned long long> h2((size_t)256 * 96);
+    std::vector<unsigned long long> h2((size_t)256 * 96 + 2048 + 512);
     CK(hipMemcpy(h2.data(), dbg, h2.size() * 8, hipMemcpyDeviceToHost));
     const char* nm[12] = {"wait E' (x DMA landed)", "conv, stats, S1 publish n", "wait A", "S2 gate/sigmoid/dgpre", "wait B", "P2 gate wgrad",
                           "S3 gateT/GN bwd", "wait C", "DMA issue, dy loads, P3 publish", "wait D", "dx convT + store", "P4 conv wgrad (+prologue)"};
@@ -69,6 +79,25 @@ int main(int argc, char** argv) {
       printf("phase %2d %-36s %8.0f cycles / tile (mean over waves)\n", ph, nm[ph], sum);
     }
     printf("total %.0f cycles / tile\n", tot);
+    {
+      double mx = 0, mn = 1e30, av = 0;
+      for (size_t b = 0; b < 256; ++b) for (int w = 0; w < 8; ++w) {
+        double t = 0;
+        for (int ph = 0; ph < 12; ++ph) t += (double)h2[b * 96 + w * 12 + ph];
+        mx = std::max(mx, t); mn = std::min(mn, t); av += t / 2048.0;
+      }
+      printf("per wave, whole tile loop: min %.0f  mean %.0f  max %.0f cycles\n", mn, av, mx);
+      double cy = 0, rt = 0;
+      for (int b = 0; b < 256; ++b) { cy += (double)h2[(size_t)256 * 96 + 2048 + 2 * b]; rt += (double)h2[(size_t)256 * 96 + 2048 + 2 * b + 1]; }
+      printf("workgroup lifetime: %.0f shader cycles = %.1f us of the 100 MHz clock -> %.3f GHz\n", cy / 256, rt / 256 / 100.0, cy / rt / 10.0);
+    }
+#ifdef B4_STAMPS
+    for (int b = 0; b < 3; ++b) {
+      printf("workgroup %d: SIMD of waves 0..7:", b);
+      for (int w = 0; w < 8; ++w) printf(" %llu", h2[(size_t)256 * 96 + b * 8 + w]);
+      printf("\n");
+    }
+#endif
   }
   return 0;
 }

@@ -805,6 +805,10 @@ extern "C" {
 
 // test hook: 1 routes every hot backward through the 8-wave kernel of this file (mask / ragged-tile path), 0 restores the dispatch
 int frl_tcn_hot_force_generic_tiles(int on) { const int was = g_th_force_bwd2; g_th_force_bwd2 = on; return was; }
+// 4 (default): tcn_hot_bwd4_kernel (two independent 4-wave subgroups per workgroup); 3: tcn_hot_bwd3_kernel (8 waves in lockstep).  Returns the
+// previous value; for A/B measurements and the parity tests of both kernels.
+static int g_th_bwd_variant = 4;
+int frl_tcn_hot_bwd_variant(int v) { const int was = g_th_bwd_variant; if (v == 3 || v == 4) g_th_bwd_variant = v; return was; }
 
 // 1 when the specialised kernels apply: bf16, 64 -> 64 channels, T = 5, 8 groups, identity residual, dilation 1 / 2 / 4
 int frl_tcn_hot_supported(int T, int Cin, int Cout, int G, int dilation, int has_proj, int dtype) {
@@ -882,8 +886,10 @@ int frl_tcn_hot_bwd(const void* x, const void* drop_mask, const void* dy, const 
   int rc = -2;
   if (dx == nullptr && !(drop_mask == nullptr && th_bwd3_supported(npix, HW) && !g_th_force_bwd2))
     return frl_fail(-2, "tcn_hot_bwd: dx may be NULL (input without gradient) only on the tcn_hot_bwd3 route (no mask, HW % 64 == 0)");
-  if (drop_mask == nullptr && th_bwd3_supported(npix, HW) && !g_th_force_bwd2)      // the measured configuration: tcn_hot_bwd3.hip
-    rc = th_bwd3_launch(dilation, x, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
+  if (drop_mask == nullptr && th_bwd3_supported(npix, HW) && !g_th_force_bwd2)      // the measured configuration: tcn_hot_bwd4.hip / tcn_hot_bwd3.hip
+    rc = (g_th_bwd_variant == 4 && th_bwd4_supported(npix, HW))
+             ? th_bwd4_launch(dilation, x, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream)
+             : th_bwd3_launch(dilation, x, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
   else if (dilation == 1) rc = th_launch_bwd<1>(x, drop_mask, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
   else if (dilation == 2) rc = th_launch_bwd<2>(x, drop_mask, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
   else if (dilation == 4) rc = th_launch_bwd<4>(x, drop_mask, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);

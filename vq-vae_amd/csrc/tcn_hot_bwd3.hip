@@ -189,6 +189,7 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __rest
   unsigned long long* b3_ts = reinterpret_cast<unsigned long long*>(smem + B3_GACC + 2048);   // [8 waves][12]
   if (tid < 96) b3_ts[tid] = 0ull;
   unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_start = t_prev, r_start = __builtin_amdgcn_s_memrealtime();
 #endif
   f32x4 accC[3][2], accG[2], accB = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -471,6 +472,10 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd3_kernel(const bf16* __rest
   B3_BARRIER_ALL();
 #ifdef B3_STAMPS
   if (tid < 96) b3_dbg[(size_t)blockIdx.x * 96 + tid] = b3_ts[tid];
+  if (tid == 0) {                                                  // shader-clock cycles and 100 MHz ticks of the whole tile loop
+    b3_dbg[(size_t)gridDim.x * 96 + 2048 + 2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_start;
+    b3_dbg[(size_t)gridDim.x * 96 + 2048 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r_start;
+  }
 #endif
   // ---------------- write this workgroup's slab (rows 16q.., columns 32h..) ----------------
   B3_ADDR();

@@ -123,6 +123,7 @@ SIGNATURES = {
     "frl_tcn_hot_fwd": (c_int, [P, P, P, P, P, P, P, P, P, L, I, I, F, P, S, P]),
     "frl_tcn_hot_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, F, P, S, P]),
     "frl_tcn_hot_force_generic_tiles": (c_int, [I]),
+    "frl_tcn_hot_bwd_variant": (c_int, [I]),
     "frl_tcn_hot_bwd_nodx_supported": (c_int, [L, I]),
     "frl_tcn_chain_fwd_workspace_bytes": (S, []),
     "frl_tcn_chain_fwd": (c_int, [P] * 13 + [L, I, I, F, P, S, P]),
