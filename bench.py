@@ -323,7 +323,7 @@ def main():
         # --- dominant kernel -> headline roofline object
         # dominant kernel FAMILY among those with a per-launch work model below (the fused TCN kernels at the measured configuration)
         # (kernel families with a per-launch work model; time = the library-side event pairs around the kernel launches themselves)
-        fam = {"tcn_block_bwd.main": "tcn_hot_bwd3_kernel", "tcn_block_bwd.nodx": "tcn_hot_bwd3_nodx_kernel", "tcn_block_fwd": "tcn_hot_fwd",
+        fam = {"tcn_block_bwd.main": "tcn_hot_bwd4_kernel", "tcn_block_bwd.nodx": "tcn_hot_bwd4_nodx_kernel", "tcn_block_fwd": "tcn_hot_fwd",
                "tcn_chain_fwd": "tcn_chain_fwd_kernel", "vq_assign": "vq_assign_kernel", "edge_smooth_fwd": "smooth_fwd_bf16",
                "edge_smooth_bwd": "smooth_bwd_bf16", "smooth_heads_fwd": "smooth_heads_fwd_kernel", "smooth_heads_bwd": "smooth_heads_bwd_kernel",
                "smooth_dx": "smooth_dx"}
@@ -384,7 +384,7 @@ def profiled_kernel_us(substr):
 
 def pmc_traffic(name):
     """HBM bytes per launch from the newest committed rocprofv3 --pmc passes (profiles/*_pmc.json), or None."""
-    key = {"tcn_block_bwd.main": "tcn_hot_bwd3_kernel<", "tcn_block_bwd.nodx": "tcn_hot_bwd3_kernel<", "tcn_block_fwd": "tcn_hot_fwd_kernel",
+    key = {"tcn_block_bwd.main": "tcn_hot_bwd4_kernel<", "tcn_block_bwd.nodx": "tcn_hot_bwd4_kernel<", "tcn_block_fwd": "tcn_hot_fwd_kernel",
            "tcn_chain_fwd": "tcn_chain_fwd_kernel", "vq_assign": "vq_assign", "edge_smooth_bwd": "smooth_bwd_bf16r4_kernel",
            "smooth_heads_fwd": "smooth_heads_fwd_kernel", "smooth_heads_bwd": "smooth_heads_bwd_kernel", "smooth_dx": "smooth_dx",
            "conv1x1_bwd_weight": "pw_wgrad_kernel"}.get(name)
@@ -435,8 +435,8 @@ def roofline_for(name, ksum, args, model, n, s):
         base.update(first)
         base["other_ceiling"] = second
         base["note"] = ("HIP-event pair inside the library around the kernel launch itself (weight pack and slab reduction of the C-ABI call "
-                        "excluded); per tile the vector ALU, the matrix cores and the LDS each need ~7.5k cycles and the phases run them "
-                        "one after the other (~30k cycles): DESIGN.md section 4")
+                        "excluded); issue-bound: ~1770 vector-ALU instructions and 226 MFMAs per wave and 32-pixel tile, two waves per SIMD "
+                        "(one of each subgroup): DESIGN.md section 4")
         return base
     if name == "vq_assign":
         b = n * (2 * d * s + 4) + args.codebook * d * 4

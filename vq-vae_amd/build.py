@@ -19,6 +19,23 @@ OUT = os.path.join(HERE, "frl_hip", "libfrlhip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result",
          "-I", CSRC, "-I", os.path.join(os.path.dirname(HERE), "include")]
+# A/B builds: FRL_BUILD_TAG=x python build.py --force  ->  build_x/*.o, frl_hip/libfrlhip_x.so (loaded when FRL_HIP_LIB_TAG=x), compiled
+# with FRL_EXTRA_FLAGS appended
+TAG = os.environ.get("FRL_BUILD_TAG", "")
+if TAG:
+    OBJ = os.path.join(HERE, "build_" + TAG)
+    OUT = os.path.join(HERE, "frl_hip", f"libfrlhip_{TAG}.so")
+FLAGS += os.environ.get("FRL_EXTRA_FLAGS", "").split()
+
+
+def file_flags(src: str):
+    """Per-file compiler flags: a line `// build-flags: ...` among the first 40 lines of the source."""
+    out = []
+    with open(src) as f:
+        for _, line in zip(range(40), f):
+            if line.startswith("// build-flags:"):
+                out += line[len("// build-flags:"):].split()
+    return out
 
 
 def _newer(src: str, dst: str, deps) -> bool:
@@ -40,7 +57,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def cc(job):
         s, o = job
-        r = subprocess.run([HIPCC] + FLAGS + ["-c", s, "-o", o], capture_output=True, text=True)
+        r = subprocess.run([HIPCC] + FLAGS + file_flags(s) + ["-c", s, "-o", o], capture_output=True, text=True)
         return s, r.returncode, r.stdout + r.stderr
 
     if jobs:

@@ -10,7 +10,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfrlhip.so")
+# FRL_HIP_LIB_TAG=x loads libfrlhip_x.so (an A/B build made with FRL_BUILD_TAG=x python build.py); there is no other fallback
+LIB_PATH = os.path.join(_HERE, "libfrlhip_%s.so" % os.environ["FRL_HIP_LIB_TAG"] if os.environ.get("FRL_HIP_LIB_TAG") else "libfrlhip.so")
 
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
