@@ -50,6 +50,8 @@ def parse():
                     help="run the phase branch on the main stream (per-kernel profiling: no overlap between the two branches)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; nccl == RCCL (the measured configuration), gloo only to rehearse the N>1 control flow")
+    ap.add_argument("--no-defer-reductions", action="store_true",
+                    help="A/B: one slab-reduction launch behind every weight-gradient kernel instead of one launch for all of them")
     ap.add_argument("--torch-optimizer", action="store_true", help="A/B: clip_grad_norm_ + torch.optim.AdamW instead of the two HIP launches")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the train step from a captured hipGraph (VQVAETrainer.step_graphed); auto: whenever the trainer supports it")
@@ -143,7 +145,8 @@ def build_trainer(args, dev, dtype, codebook, emb_dim, phase_codebook=0, serial=
     if init_tile is not None:
         model.init_codebook_from_tiles(init_tile, seed=7)
     model.concurrent_phase = not serial
-    trainer = VQVAETrainer(model, lr=1e-4, total_steps=10000, check_finite=not args.no_finite_check, fused_optimizer=not args.torch_optimizer)
+    trainer = VQVAETrainer(model, lr=1e-4, total_steps=10000, check_finite=not args.no_finite_check, fused_optimizer=not args.torch_optimizer,
+                           defer_reductions=not args.no_defer_reductions)
     return model, trainer
 
 

@@ -222,6 +222,22 @@ int frl_tcn_block_bwd_fused(const void* x, const void* dy, const float* conv_w, 
                             float* d_conv_b, float* d_gn_w, float* d_gn_b, float* d_gate_w, float* d_gate_b, int64_t npix,
                             int HW, int T, int dilation, int G, float eps, void* ws, size_t ws_bytes, frl_stream_t stream);
 
+/* ---- deferred weight-gradient reductions (csrc/defer.hip) -------------------------------------------------------------------------
+ * Every weight-gradient kernel leaves per-workgroup float32 slabs that a small fixed-order reduction turns into the gradient tensors.
+ * Between frl_defer_begin() and frl_defer_flush(stream) those reductions (of frl_tcn_hot_bwd, frl_conv3x3_bwd_weight,
+ * frl_decoder_mse_bwd, frl_encoder2_bwd, frl_film_fused_bwd, frl_smooth_heads_bwd and frl_conv1x1_bwd_weight; calls that cut their
+ * output channels into several slices are not deferred, nor is the codebook gradient, whose epilogue reads tensors of the backward pass)
+ * are parked and the flush runs them all in ONE launch: same summation order, bit-identical gradients, ~12 launches fewer per
+ * train step.  The caller owns two promises: the workspaces handed to the deferred calls stay untouched until the flush (hand every
+ * call its own), and nothing reads the gradient tensors before it.  frl_defer_destinations lists the gradient pointers of the parked
+ * jobs so that the caller can check they still are the tensors its optimizer reads.  Process-wide state (any thread's calls are
+ * parked); at most 24 jobs, further ones run undeferred.  frl_defer_flush returns the number of jobs run. */
+int frl_defer_begin(void);
+int frl_defer_pending(void);
+int frl_defer_destinations(void** out, int max);
+int frl_defer_flush(hipStream_t stream);
+int frl_defer_abort(void);
+
 /* hot-configuration block kernels (bf16, Cin = Cout = 64, T = 5, G = 8, identity residual, dilation 1/2/4: the three phase-path
  * blocks of configs/vae_v0.yaml): (T, dilation) are compile-time, the pixel's time series stays in registers, the temporal
  * conv is evaluated once per tile.  frl_tcn_hot_bwd is one launch for dx + every parameter gradient (tcn.py:78-111). */

@@ -494,6 +494,65 @@ def test_weight_image_cache_changes_nothing_but_the_launch_count():
         assert torch.equal(p, q), n
 
 
+def test_deferred_reductions_change_nothing_but_the_launch_count():
+    """VQVAETrainer(defer_reductions=True): the slab reductions behind the weight-gradient kernels of the backward pass (fused TCN blocks,
+    3x3 / 1x1 weight gradients, fused encoder / decoders / FiLM / mixing heads, codebook gradient) are parked and run in ONE launch before
+    the optimizer (csrc/defer.hip).  Same summation order: three eager steps and three graph replays with and without deferral end in EQUAL
+    parameters; the deferred backward must have parked at least ten jobs; and a backward in which autograd sums two gradients of one
+    parameter (used twice) is refused instead of reading a tensor nothing has written yet."""
+    from frl_hip import _lib, ops
+    from frl_hip.models import VQVAE
+    from frl_hip.training.trainer import VQVAETrainer
+
+    def make():
+        torch.manual_seed(0)
+        m = VQVAE(in_features=64, codebook_size=64, emb_dim=64, beta=0.25, type_encoder_dropout=0.0, phase_tcn_dropout=0.0,
+                  compute_dtype=torch.bfloat16).to(DEV)
+        with torch.no_grad():
+            m.quant.codebook.copy_(torch.randn(64, 64, generator=torch.Generator().manual_seed(7)))
+        return m
+
+    g = torch.Generator().manual_seed(13)
+    tiles = [torch.randn(2, 5, 32, 32, 64, generator=g).to(torch.bfloat16).to(DEV) for _ in range(3)]
+    lib = _lib.load()
+    for graphed in (False, True):
+        runs = []
+        for defer in (False, True):
+            m = make()
+            tr = VQVAETrainer(m, lr=1e-3, total_steps=10, defer_reductions=defer)
+            seen = []
+            if defer and not graphed:                                  # count the parked jobs of the first step
+                orig_exit = ops.deferred_reductions.__exit__
+
+                def counting_exit(self, et, ev, tb):
+                    seen.append(lib.frl_defer_pending())
+                    return orig_exit(self, et, ev, tb)
+                ops.deferred_reductions.__exit__ = counting_exit
+            try:
+                losses = [float((tr.step_graphed(t) if graphed else tr.step(t))["loss"].detach()) for t in tiles]
+            finally:
+                if defer and not graphed:
+                    ops.deferred_reductions.__exit__ = orig_exit
+            if defer and not graphed:
+                assert seen and min(seen) >= 10, seen
+            assert lib.frl_defer_pending() == 0
+            runs.append((m, losses))
+        (m0, l0), (m1, l1) = runs
+        assert l0 == l1, (graphed, l0, l1)
+        for (n, p), (_, q) in zip(m0.named_parameters(), m1.named_parameters()):
+            assert torch.equal(p, q), (graphed, n)
+
+    # a parameter with two consumers: autograd adds the two weight gradients at backward time -> refused
+    from frl_hip import functional as Fh
+    w = torch.nn.Parameter(torch.randn(64, 64, device=DEV) * 0.1)
+    x = torch.randn(4096, 64, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    with pytest.raises(RuntimeError, match="deferred_reductions"):
+        y = Fh.conv1x1(Fh.conv1x1(x, w), w)
+        with ops.deferred_reductions([w]):
+            y.float().sum().backward()
+    assert lib.frl_defer_pending() == 0 and lib.frl_defer_begin() == 0 and lib.frl_defer_abort() == 0     # nothing left open
+
+
 def test_configs1_train_step_end_to_end():
     """BASELINE configs[1] as bench.py measures it (256 tiles of 5x32x32x64, K = 512, d = 64, bf16): one full train step through the
     HIP path -- VQ indices are the exact float64 argmin of the latents the encoder produced, every loss term is finite, parameters move."""

@@ -591,20 +591,6 @@ __global__ __launch_bounds__(64 * NWV) void conv3x3_wgrad_kernel(const T* __rest
 }
 
 // epilogue of the slab reduction: out[oc][j] = sum_wg slab[wg][ocl][j]; rows beyond Cout are dropped
-struct C3Epi {
-  int OCT, Cin9, oc_base, Cout; float* dW; float* dB;
-  __device__ void operator()(int64_t i, float s) const {
-    if (i < (int64_t)OCT * Cin9) {
-      const int Cin = Cin9 / 9;
-      const int tap = (int)(i / ((int64_t)OCT * Cin)), rem = (int)(i % ((int64_t)OCT * Cin));
-      const int ocl = rem / Cin, ic = rem % Cin;
-      if (oc_base + ocl < Cout) dW[(int64_t)(oc_base + ocl) * Cin9 + ic * 9 + tap] = s;
-    } else if (dB != nullptr) {
-      const int ocl = (int)(i - (int64_t)OCT * Cin9);
-      if (oc_base + ocl < Cout) dB[oc_base + ocl] = s;
-    }
-  }
-};
 
 // ------------------------------------------------------------------------------------------------
 // host
@@ -743,7 +729,8 @@ int frl_conv3x3_bwd_weight(const void* dy, const void* y, int act, const void* x
       FRL_LAUNCH_AS("conv3x3_wgrad_kernel", kern, dim3(nwg), dim3(512), lds, stream, (const bf16*)dy, (const bf16*)ym, act, (const bf16*)x, (float*)ws, B,
                          H, W, Cin, Cout, oc_base, tpw, (flags & 1) ? 0 : 1);
     } else return frl_fail(-2, "conv3x3_bwd_weight: bad dtype");
-    launch_slab_reduce<float, C3Epi>((const float*)ws, nwg, slab_n, C3Epi{64, Cin * 9, oc_base, Cout, dw, dbias}, stream);
+    launch_slab_reduce_deferrable<float, C3Epi>((const float*)ws, nwg, slab_n, C3Epi{64, Cin * 9, oc_base, Cout, dw, dbias}, stream,
+                                                Cout <= 64);      // (deferrable only when this is the call's single slice: the slices share `ws`)
   }
   return frl_check_launch("conv3x3_bwd_weight");
 }

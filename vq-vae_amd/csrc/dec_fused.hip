@@ -357,18 +357,6 @@ static const frag8* dec_packed(const float* w1, const float* w2, int Cz, int bwd
   return pk;
 }
 
-template <int NFZ>
-struct DecEpi {
-  float *dW2, *dW1, *db2, *db1; int Cz;
-  __device__ void operator()(int64_t i, float s) const {
-    constexpr int CZP = 32 * NFZ;
-    if (i < DF_F * DF_H) { dW2[i] = s; return; }
-    i -= DF_F * DF_H;
-    if (i < DF_H * CZP) { const int hh = (int)(i / CZP), c = (int)(i % CZP); if (c < Cz) dW1[hh * Cz + c] = s; return; }
-    i -= DF_H * CZP;
-    if (i < DF_F) db2[i] = s; else db1[i - DF_F] = s;
-  }
-};
 
 static unsigned df_fwd_grid(int64_t P) { int64_t g = ((P + 15) / 16 + 3) / 4; if (g > DF_GRID_MAX) g = DF_GRID_MAX; return (unsigned)(g < 1 ? 1 : g); }
 static unsigned df_bwd_grid(int64_t P, int R) { int64_t g = (P + R - 1) / R; if (g > 256) g = 256; return (unsigned)(g < 1 ? 1 : g); }
@@ -387,7 +375,7 @@ static int launch_dec_bwd(const void* z, const float* w1, const float* b1, const
   FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   FRL_LAUNCH_AS("dec_mse_bwd_kernel", kern, dim3(grid), dim3(64 * NW), lds, st, (const TT*)z, (const frag8*)pk, b1, b2, (const TT*)tgt, mask, gscale, stats, (TT*)dz, P, Cz,
              (float*)ws);
-  launch_slab_reduce<float, DecEpi<NFZ>>((const float*)ws, (int)grid, (int64_t)slab_n, DecEpi<NFZ>{dw2, dw1, db2, db1, Cz}, st);
+  launch_slab_reduce_deferrable<float, DecEpi>((const float*)ws, (int)grid, (int64_t)slab_n, DecEpi{dw2, dw1, db2, db1, Cz, CZP, DF_F, DF_H}, st);
   return frl_check_launch("decoder_mse_bwd");
 }
 

@@ -528,19 +528,6 @@ __global__ __launch_bounds__(EF_NTH) void enc2_bwd_kernel(const TT* __restrict__
   }
 }
 
-struct EncEpi {
-  float *dw2, *dw1, *db2, *dg2, *db1, *dg1;
-  __device__ void operator()(int64_t i, float s) const {
-    if (i < EF_C2 * EF_C1) { dw2[i] = s; return; }
-    i -= EF_C2 * EF_C1;
-    if (i < EF_C1 * EF_C0) { dw1[i] = s; return; }
-    i -= EF_C1 * EF_C0;
-    if (i < 64) db2[i] = s;
-    else if (i < 128) dg2[i - 64] = s;
-    else if (i < 256) db1[i - 128] = s;
-    else dg1[i - 256] = s;
-  }
-};
 
 static const frag8* enc_packed(const float* w1, const float* w2, int bwd, frag8* ws_pk, hipStream_t st) {
   FrlPackJob jobs[3];
@@ -603,7 +590,7 @@ int frl_encoder2_bwd(const void* x, const void* dz, const float* w1, const float
   auto kern = enc2_bwd_kernel;
   FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EF_LDS_BWD));
   FRL_LAUNCH(enc2_bwd_kernel, dim3(B), dim3(EF_NTH), EF_LDS_BWD, stream, (const TT*)x, (const TT*)dz, pk, g1, b1, g2, b2, stats, (float*)ws, HW);
-  launch_slab_reduce<float, EncEpi>((const float*)ws, B, (int64_t)EF_SLAB2, EncEpi{dw2, dw1, db2, dg2, db1, dg1}, stream);
+  launch_slab_reduce_deferrable<float, EncEpi>((const float*)ws, B, (int64_t)EF_SLAB2, EncEpi{dw2, dw1, db2, dg2, db1, dg1}, stream);
   return frl_check_launch("encoder2_bwd");
 }
 

@@ -290,19 +290,6 @@ __global__ __launch_bounds__(256) void film_fused_bwd_kernel(const bf16* __restr
   }
 }
 
-struct FilmEpi {
-  float *dw1g, *dw1b, *dw2g, *dw2b, *db1g, *db1b, *db2g, *db2b;
-  __device__ void operator()(int64_t i, float s) const {
-    if (i < 2048) { dw1g[i] = s; return; }
-    if (i < 4096) { dw1b[i - 2048] = s; return; }
-    if (i < 4480) { dw2g[i - 4096] = s; return; }
-    if (i < 4864) { dw2b[i - 4480] = s; return; }
-    if (i < 4896) { db1g[i - 4864] = s; return; }
-    if (i < 4928) { db1b[i - 4896] = s; return; }
-    if (i < 4940) { db2g[i - 4928] = s; return; }
-    db2b[i - 4940] = s;
-  }
-};
 
 extern "C" {
 
@@ -346,7 +333,7 @@ int frl_film_fused_bwd(const void* z_type, const void* h, const void* dz, const 
   const size_t lds = (size_t)FF_FR_BWD * sizeof(frag8) + 96 * sizeof(float) + (size_t)FFB_R * (3 * FFB_P64 + FFB_P32) * sizeof(bf16);
   FRL_LAUNCH(film_fused_bwd_kernel, dim3((unsigned)g), dim3(256), lds, stream, (const bf16*)z_type, (const bf16*)h, (const bf16*)dz, pk, b1g, b1b, b2g,
              b2b, (bf16*)dh, slab, npix, HW, T);
-  launch_slab_reduce<float, FilmEpi>((const float*)slab, (int)g, (int64_t)FF_SLAB, FilmEpi{dw1g, dw1b, dw2g, dw2b, db1g, db1b, db2g, db2b}, stream);
+  launch_slab_reduce_deferrable<float, FilmEpi>((const float*)slab, (int)g, (int64_t)FF_SLAB, FilmEpi{dw1g, dw1b, dw2g, dw2b, db1g, db1b, db2g, db2b}, stream);
   return frl_check_launch("film_fused_bwd");
 }
 

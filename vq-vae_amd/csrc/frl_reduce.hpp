@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "frl_host.hpp"
+#include "frl_epi.hpp"
+#include <string.h>
 
 template <typename V, class Epi>
 __global__ __launch_bounds__(256) void slab_reduce_t(const V* __restrict__ slab, int nslab, int64_t n, Epi epi) {
@@ -41,4 +43,33 @@ template <typename V, class Epi>
 static inline void launch_slab_reduce(const V* slab, int nslab, int64_t n, Epi epi, hipStream_t st) {
   const unsigned grid = (unsigned)((n + 31) / 32);
   FRL_LAUNCH((slab_reduce_t<V, Epi>), dim3(grid), dim3(256), 0, st, slab, nslab, n, epi);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Deferred reductions (defer.hip).  Between frl_defer_begin() and frl_defer_flush(stream) a deferrable reduction is not launched: its
+// slab pointer, shape and epilogue are appended to a job list, and the flush runs every job in ONE launch.  The caller guarantees that
+// the slabs (the workspaces of the deferred calls) stay untouched until the flush and that nothing reads the gradients before it.
+#define FRL_DEFER_MAX_JOBS 24
+#define FRL_DEFER_PAYLOAD 72
+struct FrlDeferJob {
+  const float* slab;
+  int64_t n;
+  int nslab, kind;
+  unsigned first_block, pad_;
+  unsigned char payload[FRL_DEFER_PAYLOAD];
+};
+int frl_defer_active_();                                  // 1 between begin and flush
+int frl_defer_push_(const FrlDeferJob& job);              // 1 when the job was taken (0: list full -> the caller launches as usual)
+
+template <typename V, class Epi>
+static inline void launch_slab_reduce_deferrable(const V* slab, int nslab, int64_t n, Epi epi, hipStream_t st, bool allow = true) {
+  static_assert(FrlEpiKind<Epi>::id != 0 && sizeof(Epi) <= FRL_DEFER_PAYLOAD && sizeof(V) == sizeof(float), "not a deferrable epilogue");
+  if (allow && frl_defer_active_()) {
+    FrlDeferJob job;
+    memset(&job, 0, sizeof(job));
+    job.slab = (const float*)slab; job.n = n; job.nslab = nslab; job.kind = FrlEpiKind<Epi>::id;
+    memcpy(job.payload, &epi, sizeof(Epi));
+    if (frl_defer_push_(job)) return;
+  }
+  launch_slab_reduce<V, Epi>(slab, nslab, n, epi, st);
 }

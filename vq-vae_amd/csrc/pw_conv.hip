@@ -189,7 +189,9 @@ extern "C" {
 
 // workspace for the packed-weight image of any pointwise / 3-tap / 3x3 convolution of this library
 size_t frl_conv_workspace_bytes(int Cin, int Cout, int taps) {
-  const size_t ci = (size_t)(Cin + 31) / 32 * 32, co = (size_t)(Cout + 15) / 16 * 16;
+  // packed images pad the contraction width to a whole fragment chunk (<= 64 channels) and the output rows to blocks of four 16-row
+  // MFMA tiles, in either direction (the backward-data calls swap the roles): both widths are rounded up to 64
+  const size_t ci = (size_t)(Cin + 63) / 64 * 64, co = (size_t)(Cout + 63) / 64 * 64;
   return (size_t)taps * ci * co * sizeof(float) + 4096;
 }
 

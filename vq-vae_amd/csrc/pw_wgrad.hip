@@ -239,18 +239,6 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(
 
 // Epilogue of the fixed-order slab reduction (frl_reduce.hpp).  dw strides let the caller scatter a tap slice of a
 // [Cout][Cin][ntap] tensor: dst = dW[oc * dso + ic * dsi].
-struct WgradEpi {
-  float* dW; int64_t dso, dsi; float* dB; int Cout, Cin, accumulate_bias;
-  __device__ void operator()(int64_t i, float s) const {
-    if (i < (int64_t)Cout * Cin) {
-      const int oc = (int)(i / Cin), ic = (int)(i % Cin);
-      dW[oc * dso + ic * dsi] = s;
-    } else if (dB != nullptr) {
-      const int oc = (int)(i - (int64_t)Cout * Cin);
-      if (accumulate_bias) dB[oc] += s; else dB[oc] = s;
-    }
-  }
-};
 
 static int g_wgrad_max_wgs = 512;     // A/B at BASELINE configs[1] (tools/wgrad_bench.py): 512 beats 1024 (slab traffic) and 256 (latency hiding)
 static int wgrad_nwg(int64_t P) {
@@ -319,9 +307,11 @@ size_t frl_conv1x1_bwd_weight_workspace_bytes(int64_t P, int Cin, int Cout) {
 // dW destination strides (dso, dsi) let one call fill tap `k` of a [Cout][Cin][ntap] tensor.
 // flags: bit0 = use scalar LDS fragment reads instead of ds_read_b64_tr_b16 (debug / A-B check),
 //        bit1 = accumulate into dbias instead of overwriting.
-int frl_conv_tap_bwd_weight(const void* dy, const void* y, int act, const void* x, float* dw, int64_t dso,
-                            int64_t dsi, float* dbias, int64_t P, int Cin, int Cout, int HW, int T, int toff,
-                            int dtype, void* ws, size_t ws_bytes, int flags, hipStream_t stream) {
+// (may_defer: the slab reduction may be parked for frl_defer_flush -- only the plain 1x1 call with a single output slice asks for it: the
+// slices of one call share the workspace, and the taps of a dilated convolution accumulate into one bias gradient in call order)
+static int conv_tap_bwd_weight(const void* dy, const void* y, int act, const void* x, float* dw, int64_t dso,
+                               int64_t dsi, float* dbias, int64_t P, int Cin, int Cout, int HW, int T, int toff,
+                               int dtype, void* ws, size_t ws_bytes, int flags, hipStream_t stream, bool may_defer) {
   if (P <= 0) return frl_fail(-2, "bwd_weight: empty input");
   if (ws_bytes < frl_conv1x1_bwd_weight_workspace_bytes(P, Cin, Cout)) return frl_fail(-4, "bwd_weight: workspace too small");
   const void* ym = act != FRL_ACT_NONE ? y : nullptr;
@@ -339,16 +329,24 @@ int frl_conv_tap_bwd_weight(const void* dy, const void* y, int act, const void* 
     else return frl_fail(-2, "bwd_weight: bad dtype");
     if (rc) return rc;
     const int64_t n = (int64_t)co * Cin + co;
-    launch_slab_reduce<float, WgradEpi>((const float*)ws, wgrad_nwg(P), n,
-                                        WgradEpi{dw + (int64_t)oc0 * dso, dso, dsi, dbias ? dbias + oc0 : nullptr, co, Cin, (flags & 2) ? 1 : 0}, stream);
+    launch_slab_reduce_deferrable<float, WgradEpi>((const float*)ws, wgrad_nwg(P), n,
+                                        WgradEpi{dw + (int64_t)oc0 * dso, dso, dsi, dbias ? dbias + oc0 : nullptr, co, Cin, (flags & 2) ? 1 : 0}, stream,
+                                        may_defer && Cout <= 256 && (flags & 2) == 0);
   }
   return frl_check_launch("slab_reduce");
 }
 
+int frl_conv_tap_bwd_weight(const void* dy, const void* y, int act, const void* x, float* dw, int64_t dso,
+                            int64_t dsi, float* dbias, int64_t P, int Cin, int Cout, int HW, int T, int toff,
+                            int dtype, void* ws, size_t ws_bytes, int flags, hipStream_t stream) {
+  // (the plain 1x1 form -- dense [Cout][Cin] destination, no time shift -- is what frl_conv1x1_bwd_weight issues: deferrable as well)
+  const bool plain = dso == Cin && dsi == 1 && T == 1 && toff == 0;
+  return conv_tap_bwd_weight(dy, y, act, x, dw, dso, dsi, dbias, P, Cin, Cout, HW, T, toff, dtype, ws, ws_bytes, flags, stream, plain);
+}
+
 int frl_conv1x1_bwd_weight(const void* dy, const void* y, int act, const void* x, float* dw, float* dbias,
                            int64_t P, int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
-  return frl_conv_tap_bwd_weight(dy, y, act, x, dw, Cin, 1, dbias, P, Cin, Cout, 1, 1, 0, dtype, ws, ws_bytes, 0,
-                                 stream);
+  return conv_tap_bwd_weight(dy, y, act, x, dw, Cin, 1, dbias, P, Cin, Cout, 1, 1, 0, dtype, ws, ws_bytes, 0, stream, true);
 }
 
 }  // extern "C"

@@ -472,16 +472,6 @@ __global__ __launch_bounds__(64 * SHB_NW, 2) void smooth_heads_bwd_kernel(const 
   }
 }
 
-struct ShEpi {
-  float *dwb, *dwa, *dbb, *dba;
-  __device__ void operator()(int64_t i, float s) const {
-    if (i < SH_NB * SH_HID) { dwb[i] = s; return; }
-    i -= SH_NB * SH_HID;
-    if (i < SH_NA * SH_HID) { dwa[i] = s; return; }
-    i -= SH_NA * SH_HID;
-    if (i < SH_NB) dbb[i] = s; else dba[i - SH_NB] = s;
-  }
-};
 
 // ------------------------------------------------------------------------------------------------ backward, kernel 2
 // dx[p][c] = ds[p][c] / 3 + 1/3 sum_{k, +-} sum_r A[q][k][r] u[q][c][r],  q = p +- delta_k inside the image  (+ dx_add[p][c])
@@ -703,7 +693,7 @@ int frl_smooth_heads_bwd(const void* d_smoothed, const void* x, const void* feat
   FRL_HIP(hipFuncSetAttribute((const void*)smooth_heads_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   FRL_LAUNCH(smooth_heads_bwd_kernel, dim3((unsigned)g), dim3(64 * SHB_NW), lds, stream, (const bf16*)x, (const bf16*)feat, (const bf16*)d_smoothed,
              pk, ba, bb, (bf16*)dfeat, u, as, slab, B, H, W, dil);
-  launch_slab_reduce<float, ShEpi>((const float*)slab, (int)g, (int64_t)SHB_SLAB, ShEpi{dwb, dwa, dbb, dba}, stream);
+  launch_slab_reduce_deferrable<float, ShEpi>((const float*)slab, (int)g, (int64_t)SHB_SLAB, ShEpi{dwb, dwa, dbb, dba, SH_NB, SH_NA, SH_HID}, stream);
   // kernel 2: tiled through the LDS when full-width bands of TH rows (+ dil halo rows each side) make whole waves and fit, else gathers
   int TH = 0;
   if (W % 16 == 0 && W <= 512 && g_sh_force_gather == 0) {

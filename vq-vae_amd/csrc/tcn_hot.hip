@@ -731,20 +731,6 @@ __global__ void tcn_hot_pack_kernel(frag8* __restrict__ dst, const float* __rest
   for (int k = 0; k < 3; ++k) pack_weights_lds<bf16, 2>(p + k * 4 * 2 * 64, Wc + k, 64, 64, 4, 3, 64 * 3, tid, nt);   // Weff[o=ci][i=co] = Wc[co][ci][k]
 }
 
-struct ThEpi {
-  float *dWc, *dWg, *dbc, *dbg, *dgam, *dbet;
-  __device__ void operator()(int64_t i, float s) const {
-    if (i < 3 * 4096) {
-      const int k = (int)(i / 4096), co = (int)((i % 4096) / 64), ci = (int)(i % 64);
-      dWc[(co * 64 + ci) * 3 + k] = s;
-    } else if (i < 4 * 4096) {
-      dWg[i - 3 * 4096] = s;
-    } else {
-      const int j = (int)(i - 4 * 4096);
-      if (j < 64) dbc[j] = s; else if (j < 128) dbg[j - 64] = s; else if (j < 192) dgam[j - 128] = s; else dbet[j - 192] = s;
-    }
-  }
-};
 
 static unsigned th_fwd_grid(int64_t npix) {
   int64_t g = ((npix + 15) / 16 + 3) / 4;
@@ -895,7 +881,7 @@ int frl_tcn_hot_bwd(const void* x, const void* drop_mask, const void* dy, const 
   else if (dilation == 4) rc = th_launch_bwd<4>(x, drop_mask, dy, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream);
   else return frl_fail(-2, "tcn_hot_bwd: dilation must be 1, 2 or 4");
   if (rc) return rc;
-  launch_slab_reduce<float, ThEpi>((const float*)slab, (int)grid, (int64_t)TH_SLAB, ThEpi{d_conv_w, d_gate_w, d_conv_b, d_gate_b, d_gn_w, d_gn_b},
+  launch_slab_reduce_deferrable<float, ThEpi>((const float*)slab, (int)grid, (int64_t)TH_SLAB, ThEpi{d_conv_w, d_gate_w, d_conv_b, d_gate_b, d_gn_w, d_gn_b},
                                    stream);
   return frl_check_launch("tcn_hot_bwd");
 }

@@ -1243,17 +1243,6 @@ __global__ void vq_code_reduce_kernel(const float* __restrict__ slab, int nslab,
   }
 }
 
-struct CodeEpi {
-  const float* E; const int32_t* counts; const float* gscale; float ce_base; int d, bf; float* gE; float* sums_out;
-  __device__ void operator()(int64_t i, float s) const {
-    if (sums_out) sums_out[i] = s;
-    if (gE) {
-      const float ce = ce_base * (gscale ? gscale[1] : 1.f);
-      const float ev = bf ? (float)(bf16)E[i] : E[i];
-      gE[i] = ce * ((float)counts[i / d] * ev - s);
-    }
-  }
-};
 
 // EMA update (scripts/train_vqvae.py:412-414): N_k, m_k moving averages + Laplace-smoothed codebook
 // ok (optional device float): <= 0 leaves the running averages and the codebook untouched (isfinite guard of the train step)

@@ -125,6 +125,11 @@ SIGNATURES = {
     "frl_tcn_hot_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, F, P, S, P]),
     "frl_tcn_hot_force_generic_tiles": (c_int, [I]),
     "frl_tcn_hot_bwd_variant": (c_int, [I]),
+    "frl_defer_begin": (c_int, []),
+    "frl_defer_pending": (c_int, []),
+    "frl_defer_destinations": (c_int, [P, I]),
+    "frl_defer_flush": (c_int, [P]),
+    "frl_defer_abort": (c_int, []),
     "frl_tcn_hot_bwd_nodx_supported": (c_int, [L, I]),
     "frl_tcn_chain_fwd_workspace_bytes": (S, []),
     "frl_tcn_chain_fwd": (c_int, [P] * 13 + [L, I, I, F, P, S, P]),

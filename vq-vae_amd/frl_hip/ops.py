@@ -194,8 +194,63 @@ def _f32(t: Optional[torch.Tensor], name: str):
     return t
 
 
+_DEFER = {"on": False, "keep": []}
+
+
+class deferred_reductions:
+    """`with deferred_reductions(params): loss.backward()` -- the slab reductions behind the weight-gradient kernels of the backward pass
+    (csrc/defer.hip, include/frl_hip.h) are parked and run in ONE launch when the block ends, on the current stream.  While it is open every
+    kernel call gets a workspace of its own (the parked slabs live in them), kept until the flush.  Before the flush the block checks that
+    every parked destination lies inside the .grad of one of `params`: autograd must have adopted the tensors the kernels' wrappers
+    returned, not copies of them (a parameter used twice, or a hook that clones gradients, would read a tensor nothing has written yet)."""
+
+    def __init__(self, params):
+        self.params = list(params)
+
+    def __enter__(self):
+        check(_lib.load().frl_defer_begin(), "frl_defer_begin")
+        _DEFER["keep"] = []
+        _DEFER["on"] = True
+        return self
+
+    def __exit__(self, et, ev, tb):
+        lib = _lib.load()
+        _DEFER["on"] = False
+        keep, _DEFER["keep"] = _DEFER["keep"], []
+        if et is not None:
+            lib.frl_defer_abort()
+            return False
+        try:
+            buf = (ctypes.c_void_p * 512)()
+            n = lib.frl_defer_destinations(ctypes.cast(buf, ctypes.c_void_p), 512)
+            spans = sorted((g.data_ptr(), g.data_ptr() + g.numel() * g.element_size())
+                           for g in (p.grad for p in self.params) if g is not None)
+            starts = [a for a, _ in spans]
+            import bisect
+            for i in range(n):
+                d = int(buf[i])
+                k = bisect.bisect_right(starts, d) - 1
+                if k < 0 or not (spans[k][0] <= d < spans[k][1]):
+                    raise RuntimeError("deferred_reductions: a parked gradient is not the .grad of any parameter (autograd copied or summed "
+                                       "it: a parameter used twice, or a gradient hook); run this backward without deferral")
+        except Exception:
+            lib.frl_defer_abort()
+            raise
+        rc = lib.frl_defer_flush(_stream())
+        if rc < 0:
+            check(rc, "frl_defer_flush")
+        cur = torch.cuda.current_stream()
+        for t in keep:                                          # slabs written on a side stream, read by the flush on this one
+            t.record_stream(cur)
+        return False
+
+
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only per-(device, stream) scratch buffer handed to kernels that need one."""
+    """Grow-only per-(device, stream) scratch buffer handed to kernels that need one (inside `deferred_reductions`: a buffer per call)."""
+    if _DEFER["on"]:
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        _DEFER["keep"].append(ws)
+        return ws
     key = (str(device), torch.cuda.current_stream().cuda_stream)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:

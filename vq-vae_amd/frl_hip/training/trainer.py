@@ -20,8 +20,9 @@ class VQVAETrainer:
     def __init__(self, model, lr: float = 1e-4, min_lr: float = 1e-6, weight_decay: float = 0.01, max_norm: float = 1.0,
                  total_steps: int = 1000, betas=(0.9, 0.95), check_finite: bool = True, fused_optimizer: bool = True,
                  beta_schedule_cfg: Optional[dict] = None, lambda_vq_schedule: Optional[LambdaVQSchedule] = None,
-                 pack_cache: bool = True):
+                 pack_cache: bool = True, defer_reductions: bool = True):
         self.model = model
+        self.defer_reductions = bool(defer_reductions)       # single process: one launch for all weight-gradient slab reductions
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         cb = [p for n, p in named if "quant" in n and "codebook" in n]
         rest = [p for n, p in named if not ("quant" in n and "codebook" in n)]
@@ -289,6 +290,17 @@ class VQVAETrainer:
             return ok
         return (out["loss"].detach().float() * 0.0 == 0.0).float().reshape(1)
 
+    def _backward(self, loss):
+        """loss.backward(); single-process training parks the slab reductions of the weight-gradient kernels and runs them in one launch
+        (ops.deferred_reductions).  Data parallel keeps them where they are: the bucket hooks read each gradient the moment autograd
+        delivers it."""
+        if self.defer_reductions and self.hip_opt and not (self.reducer is not None and self.reducer.active):
+            from .. import ops
+            with ops.deferred_reductions(self.opt.params):
+                loss.backward()
+        else:
+            loss.backward()
+
     def _step_body(self, tile, mask):
         """forward -> device isfinite flag -> backward -> clip + AdamW -> codebook hooks -> fragment-image refresh (no host-side
         schedule, no host sync): the part of `step` that a graph can hold."""
@@ -303,7 +315,7 @@ class VQVAETrainer:
             ok_ = self._finite_flag(out_)
             if dp:
                 self.reducer.flag_src = 1.0 - ok_                  # rides in the last gradient bucket: every rank takes the same decision
-            out_["loss"].backward()                                # data parallel: the bucket hooks pack + all-reduce on the side stream
+            self._backward(out_["loss"])                           # data parallel: the bucket hooks pack + all-reduce on the side stream
             return out_, ok_
 
         if self.pack_cache is not None:
@@ -367,7 +379,7 @@ class VQVAETrainer:
                 self.step_idx += 1                                     # loops.py:110: the scheduler steps after every batch, skipped or not
                 out["lr"] = lr_now
                 return out
-        loss.backward()
+        self._backward(loss)
         if self.reducer is not None:
             self.reducer.finish(scatter=not self.hip_opt)   # HipAdamW reads the flat buckets in place
         if self.hip_opt:
