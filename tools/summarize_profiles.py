@@ -37,7 +37,8 @@ def main():
     src, name = sys.argv[1], sys.argv[2]
     os.makedirs("profiles", exist_ok=True)
     stats, tot = kernel_stats(os.path.join(src, "prof", "run_results.db"))
-    cmd = "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --serial-streams"
+    steps = max([st["calls"] for st in stats if "frl_adamw_kernel" in st["name"]] or [30])      # train steps in the profiled process
+    cmd = "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --serial-streams --graph off"
     with open(f"profiles/{name}_kernel_stats.csv", "w") as f:
         f.write("name,calls,total_ms,avg_us,min_us,max_us,pct,vgpr,agpr,sgpr,lds,scratch,grid,wg\n")
         for s in stats:
@@ -45,8 +46,8 @@ def main():
                                                                                 s["max_us"], s["pct"], s["vgpr"], s["agpr"], s["sgpr"], s["lds"],
                                                                                 s["scratch"], s["grid"], s["wg"]))
     with open(f"profiles/{name}_kernel_stats.md", "w") as f:
-        f.write(f"# {cmd}  (MI355X, {name})\n\n30 train steps in the process (5 warm-up + 20 timed + 5 event-instrumented), phase branch on the main stream so that kernel durations are not stretched by the overlap of the two branches; GPU kernel time total "
-                f"{tot:.1f} ms = {tot / 30:.3f} ms/step.\n\n| kernel | calls | total ms | avg us | % | vgpr | lds B | scratch B |\n|---|---|---|---|---|---|---|---|\n")
+        f.write(f"# {cmd}  (MI355X, {name})\n\n{steps} train steps in the process (warm-up, timed, event-instrumented and the secondary collapsed-codebook line), phase branch on the main stream so that kernel durations are not stretched by the overlap of the two branches; GPU kernel time total "
+                f"{tot:.1f} ms = {tot / steps:.3f} ms/step.\n\n| kernel | calls | total ms | avg us | % | vgpr | lds B | scratch B |\n|---|---|---|---|---|---|---|---|\n")
         for s in stats[:60]:
             f.write("| `%s` | %d | %.2f | %.1f | %.2f | %d | %d | %d |\n" % (s["name"][:90], s["calls"], s["total_ms"], s["avg_us"], s["pct"],
                                                                            s["vgpr"], s["lds"], s["scratch"]))
@@ -75,11 +76,12 @@ def main():
                 row["mfma_util"] = round(row["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024.0), 4)      # 256 CUs x 4 SIMDs
                 if row.get("SQ_WAVE_CYCLES", 0) > 0:
                     row["wave_time_waiting"] = round(row.get("SQ_WAIT_ANY", 0.0) / row["SQ_WAVE_CYCLES"], 3)
-            out[k] = {kk: (round(vv, 1) if isinstance(vv, float) else vv) for kk, vv in row.items()}
+            out[k] = {kk: (round(vv, 4 if kk in ("mfma_util", "wave_time_waiting") else 1) if isinstance(vv, float) else vv) for kk, vv in row.items()}
         conv = {}
-        for fam, subs in (("tcn_hot_bwd", ("tcn_hot_bwd",)), ("tcn_hot_fwd", ("tcn_hot_fwd",)), ("conv3x3", ("conv3x3_kernel",)),
-                          ("conv3x3_wgrad", ("conv3x3_wgrad",)), ("pw_conv", ("pw_conv_kernel",)), ("pw_wgrad", ("pw_wgrad",)),
-                          ("dec_mse", ("dec_mse_",)), ("vq_assign", ("vq_assign",))):
+        for fam, subs in (("tcn_hot_bwd", ("tcn_hot_bwd",)), ("tcn_hot_fwd", ("tcn_hot_fwd",)), ("tcn_chain_fwd", ("tcn_chain_fwd",)),
+                          ("conv3x3", ("conv3x3_kernel",)), ("conv3x3_wgrad", ("conv3x3_wgrad",)), ("pw_conv", ("pw_conv_kernel",)),
+                          ("pw_wgrad", ("pw_wgrad",)), ("dec_mse", ("dec_mse_",)), ("enc2", ("enc2_",)), ("smooth_heads", ("smooth_heads",)),
+                          ("film_fused", ("film_fused",)), ("vq_assign", ("vq_assign",))):
             hits = [v for k, v in out.items() if any(s in k for s in subs) and "mfma_util" in v]
             if hits:
                 busy = sum(h["SQ_VALU_MFMA_BUSY_CYCLES"] for h in hits)
@@ -92,7 +94,7 @@ def main():
                    "kernels": conv, "per_kernel": out}, open(f"profiles/{name}_mfma_util.json", "w"), indent=1)
     if os.path.exists(os.path.join(src, "bench.json")):
         shutil.copy(os.path.join(src, "bench.json"), f"profiles/{name}_bench.json")
-    print(f"wrote profiles/{name}_kernel_stats.md/.csv, profiles/{name}_pmc.json; total {tot / 30:.3f} ms/step")
+    print(f"wrote profiles/{name}_kernel_stats.md/.csv, profiles/{name}_pmc.json; total {tot / steps:.3f} ms/step over {steps} steps")
     for s in stats[:12]:
         print("%-70s %5d %8.1f us %6.2f%%" % (s["name"][:70], s["calls"], s["avg_us"], s["pct"]))
 
