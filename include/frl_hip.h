@@ -235,7 +235,7 @@ int frl_tcn_block_bwd_fused(const void* x, const void* dy, const float* conv_w, 
 int frl_defer_begin(void);
 int frl_defer_pending(void);
 int frl_defer_destinations(void** out, int max);
-int frl_defer_flush(hipStream_t stream);
+int frl_defer_flush(frl_stream_t stream);
 int frl_defer_abort(void);
 
 /* hot-configuration block kernels (bf16, Cin = Cout = 64, T = 5, G = 8, identity residual, dilation 1/2/4: the three phase-path
