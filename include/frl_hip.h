@@ -99,6 +99,11 @@ int frl_conv3x3_bwd_data(const void* dy, const void* y, int act, const float* w,
 int frl_conv3x3_bwd_data_fused(const void* dy, const void* y, int act, const float* w, void* dx, const void* add,
                                const void* sub_from, void* out2, int B, int H, int W, int Cin, int Cout, int dtype, void* ws,
                                size_t ws_bytes, frl_stream_t stream);
+/* dx = conv^T(dy .* act'(y)) .* out_act'(out_y): out_y [B][H][W][Cin] is the output of the ReLU / sigmoid (out_act) that the NEXT backward
+ * step differentiates through at the same pixels; that step's calls then take dx with act = FRL_ACT_NONE (no mask pass over their input:
+ * 16-35 us per 3x3 backward-data call and 6-15 us per weight-gradient call at BASELINE configs[1]). */
+int frl_conv3x3_bwd_data_outmask(const void* dy, const void* y, int act, const float* w, void* dx, const void* out_y, int out_act, int B,
+                                 int H, int W, int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, frl_stream_t stream);
 size_t frl_conv3x3_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int frl_conv3x3_bwd_weight(const void* dy, const void* y, int act, const void* x, float* dw, float* dbias, int B, int H,
                            int W, int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, int flags, frl_stream_t stream);
@@ -177,6 +182,12 @@ int frl_smooth_heads_bwd(const void* d_smoothed, const void* x, const void* feat
                          const float* bb, const void* dx_add, void* dx, void* dfeat, float* dwa, float* dba, float* dwb, float* dbb,
                          void* scratch, size_t scratch_bytes, int B, int H, int W, int coarse_dilation, void* ws, size_t ws_bytes,
                          frl_stream_t stream);
+/* The same with dfeat_relu != 0: dfeat is returned multiplied by [feat > 0] (feat is the output of the ReLU convolution mix_backbone,
+ * spatial.py:258-261), so that convolution's backward-data / backward-weight calls take it with act = FRL_ACT_NONE. */
+int frl_smooth_heads_bwd_masked(const void* d_smoothed, const void* x, const void* feat, const float* wa, const float* ba, const float* wb,
+                                const float* bb, const void* dx_add, void* dx, void* dfeat, float* dwa, float* dba, float* dwb, float* dbb,
+                                void* scratch, size_t scratch_bytes, int B, int H, int W, int dil, int dfeat_relu, void* ws,
+                                size_t ws_bytes, frl_stream_t stream);
 /* ---- FiLM conditioning of the phase path, fused (bf16, 64 conditioning channels, hidden 32, 12 target channels) ----------------------
  * Replaces FiLMLayer.forward (frl/models/conditioning.py:82-102: two conv1x1 -> ReLU -> conv1x1 nets) and the modulation
  * gamma * h + beta broadcast over T (frl/models/representation.py:369-372) with one launch per direction.  z_type [B][HW][64] is a
@@ -195,6 +206,10 @@ int frl_gate_blend_fwd(const void* smoothed, const void* residual, const void* g
                        void* gate_out, int64_t n, int dtype, frl_stream_t stream);
 int frl_gate_blend_bwd(const void* dout, const void* dgate_ext, const void* residual, const void* gate_raw, float min_gate,
                        void* d_residual, void* d_gate_raw, int64_t n, int dtype, frl_stream_t stream);
+/* The same with sigmoid_mask != 0: d_gate_raw is returned multiplied by gate_raw (1 - gate_raw), the derivative of the sigmoid that produced
+ * gate_raw (gate_net, spatial.py:266-272): the convolution's backward calls take it with act = FRL_ACT_NONE. */
+int frl_gate_blend_bwd_masked(const void* dout, const void* dgate_ext, const void* residual, const void* gate_raw, float min_gate,
+                              void* d_residual, void* d_gate_raw, int64_t n, int dtype, int sigmoid_mask, frl_stream_t stream);
 
 /* ---- fused TCN GatedResidualBlock ------------------------------------------------------------------------------
  * frl/models/tcn.py:78-111 on x [B][T][HW][Cin] (npix = B*HW); conv_w [Cout][Cin][3], gate_w [Cout][Cout],
@@ -263,6 +278,16 @@ int frl_tcn_chain_fwd(const void* x, const float* const* conv_w, const float* co
                       const float* const* gn_b, const float* const* gate_w, const float* const* gate_b, const float* head_w,
                       const float* head_b, void* y1, void* y2, void* y3, void* h, int64_t npix, int HW, int Ch, float eps, void* ws,
                       size_t ws_bytes, frl_stream_t stream);
+/* The last block of the phase encoder together with the backward-data of the 1x1 phase head behind it (representation.py:169): `dh`
+ * [B][5][HW][Ch] bf16 is the head's output gradient, head_w [Ch][64] float32, Ch in {4, 8, 12, 16}; dy = dh head_w is formed inside the
+ * kernel on the matrix cores (float32, never written).  Same outputs as frl_tcn_hot_bwd; needs the two-subgroup kernel: no mask,
+ * HW % 64 == 0, dilation 4, dx != NULL.  Workspace: frl_tcn_hot_bwd_head_workspace_bytes(npix). */
+int frl_tcn_hot_bwd_head_supported(int64_t npix, int HW, int Ch);
+size_t frl_tcn_hot_bwd_head_workspace_bytes(int64_t npix);
+int frl_tcn_hot_bwd_head(const void* x, const void* dh, const float* head_w, int Ch, const float* conv_w, const float* conv_b,
+                         const float* gn_w, const float* gn_b, const float* gate_w, const float* gate_b, void* dx, float* d_conv_w,
+                         float* d_conv_b, float* d_gn_w, float* d_gn_b, float* d_gate_w, float* d_gate_b, int64_t npix, int HW,
+                         int dilation, float eps, void* ws, size_t ws_bytes, frl_stream_t stream);
 /* Two kernels stand behind frl_tcn_hot_bwd: tcn_hot_bwd3 (no mask, HW a multiple of 64: x of a 64-pixel tile is staged once in LDS by
  * LDS-DMA, next tile prefetched) and the 8-wave kernel that also takes a mask and ragged pixel counts.  Test hook: on != 0 routes
  * every call through the latter so that the two can be compared on the same inputs. */

@@ -600,7 +600,7 @@ def test_channel_scale_dropout2d():
 
 
 @pytest.mark.parametrize("B,HW,zp", [(2, 1024, 12), (3, 100, 8), (1, 37, 16)])
-def test_phase_chain_forward_in_one_launch_equals_the_block_by_block_path(B, HW, zp):
+def test_phase_chain_forward_in_one_launch_equals_the_block_by_block_path(B, HW, zp, monkeypatch):
     """tcn_chain_fwd_kernel: the three hot GatedResidualBlocks (dilation 1, 2, 4) + the 1x1 phase head in one launch.  The blocks hand
     their outputs on in registers, rounded to bf16 exactly where the stand-alone kernels round on their store, so y1, y2, y3 must EQUAL
     the block-by-block launches bit for bit; the head agrees with the 1x1 convolution kernel to bf16 rounding; the backward (head kernels
@@ -631,7 +631,10 @@ def test_phase_chain_forward_in_one_launch_equals_the_block_by_block_path(B, HW,
     dh = torch.randn(B, 5, HW, zp, generator=torch.Generator().manual_seed(4)).to(torch.bfloat16).to(DEV)
     params = list(tcn.parameters()) + list(head.parameters())
     res = []
-    for chained in (True, False):
+    monkeypatch.setenv("FRL_HIP_DISABLE", "headbwd")                 # first with the head's backward-data as its own launch: the modular bits
+    for chained in (True, False, "head"):
+        if chained == "head":
+            monkeypatch.delenv("FRL_HIP_DISABLE")
         for p_ in params:
             p_.grad = None
         xin = x.clone().requires_grad_(True)
@@ -646,6 +649,19 @@ def test_phase_chain_forward_in_one_launch_equals_the_block_by_block_path(B, HW,
     assert torch.equal(res[0][1], res[1][1])
     for a, b in zip(res[0][2], res[1][2]):
         assert torch.equal(a, b)
+    # default route: where the last block's kernel takes dh itself (HW % 64 == 0), dy = dh W_h stays float32 inside the kernel instead of
+    # being rounded to bf16 on its way through HBM -- the same gradients to that rounding (2^-9 per element of dy), not the same bits
+    head_in_kernel = ops.tcn_block_bwd_head_supported(y2, dh, head.weight.reshape(zp, 64), 4)
+    assert head_in_kernel == (HW % 64 == 0)
+    if head_in_kernel:
+        d = (res[2][1].float() - res[0][1].float()).abs()
+        assert d.max().item() <= 1.6e-2 * res[0][1].float().abs().max().item() and d.mean().item() <= 8e-3 * res[0][1].float().abs().mean().item()
+        for a, b in zip(res[2][2], res[0][2]):
+            assert rel_err(a, b.cpu()) <= 1e-2                       # (measured 2-4e-3: tools/diag/bwd4_head_err.py)
+    else:
+        assert torch.equal(res[2][1], res[0][1])
+        for a, b in zip(res[2][2], res[0][2]):
+            assert torch.equal(a, b)
     # the chain's input is data in the model (the tile itself): block 1 then runs the backward without its conv^T GEMM / dx store;
     # parameter gradients are the same bits
     if HW % 64 == 0:
@@ -653,7 +669,7 @@ def test_phase_chain_forward_in_one_launch_equals_the_block_by_block_path(B, HW,
             p_.grad = None
         flat = [t for blk in blocks for t in blk[:6]]
         Fh.TcnChainHeadFn.apply(x, *flat, head.weight, head.bias, 8, 1e-5).backward(dh)
-        for p_, b in zip(params, res[0][2]):
+        for p_, b in zip(params, res[2][2]):
             assert torch.equal(p_.grad, b)
         g = ops.tcn_block_bwd(x, y1, *blocks[0][:6], None, None, 1, 8, want_dx=False)
         assert g["dx"] is None

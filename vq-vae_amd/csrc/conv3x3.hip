@@ -175,6 +175,8 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
   // backward pass can fold the gradient accumulation of a tensor with two consumers into the convolution that produces one of them.
   // epi_mode 1 (gate blend of EdgeAwareSmoothingConv2D, spatial.py:332-335 with min_gate = 0): Y = gate = act(conv + bias) and
   // Y2 = Yadd + gate * Ysub (Yadd = smoothed, Ysub = residual; gate taken as rounded for its store, as the stand-alone kernel reads it).
+  // epi_mode 2 / 3 (backward-data whose consumer is again a backward pass through an activation): Y = conv * act'(Yadd) with Yadd = the
+  // OUTPUT of a ReLU (2) / sigmoid (3) at the same pixel -- the next layer's backward calls then need no mask pass over their input.
   typedef typename DT<T>::frag_t frag_t;
   constexpr int FE = DT<T>::FE;
   constexpr int q = NF * FE, CK = 4 * q;
@@ -354,6 +356,14 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
             float o[DT<T>::VEC];
 #pragma unroll
             for (int e = 0; e < DT<T>::VEC; ++e) o[e] = v[j + e];
+            if (epi_mode >= 2) {
+              float m[DT<T>::VEC];
+              Vec<T>::load(Yadd + yo + j, m);
+#pragma unroll
+              for (int e = 0; e < DT<T>::VEC; ++e) o[e] *= act_bwd_from_y(m[e], epi_mode == 2 ? FRL_ACT_RELU : FRL_ACT_SIGMOID);
+              Vec<T>::store(Y + yo + j, o);
+              continue;
+            }
             if (epi_mode == 1) {
               Vec<T>::store(Y + yo + j, o);
               float a[DT<T>::VEC], r[DT<T>::VEC];
@@ -401,6 +411,10 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (cb + r >= Cout) continue;
+            if (epi_mode >= 2) {
+              yp[cb + r] = from_f32<T>(v[r] * act_bwd_from_y(to_f32(Yadd[yo + cb + r]), epi_mode == 2 ? FRL_ACT_RELU : FRL_ACT_SIGMOID));
+              continue;
+            }
             if (epi_mode == 1) {
               const T o = from_f32<T>(v[r]);
               yp[cb + r] = o;
@@ -622,7 +636,8 @@ static int launch_c3(const void* x, const void* xm, int mask_act, const float* w
   if (lds > 160 * 1024) return frl_fail(-3, "conv3x3: LDS budget exceeded");
   const bool epi = yadd != nullptr || y2 != nullptr;            // the epilogue extras are their own instantiation: the plain one keeps its registers
   // (the 32-row tile keeps the halo prefetch of a convolution without an activation mask -- every forward call -- to half the registers)
-  auto kern = tall ? (epi ? conv3x3_kernel<T, NF, true, 32, true> : (xm != nullptr ? conv3x3_kernel<T, NF, false, 32, true> : conv3x3_kernel<T, NF, false, 32, false>))
+  auto kern = tall ? (epi ? (xm != nullptr ? conv3x3_kernel<T, NF, true, 32, true> : conv3x3_kernel<T, NF, true, 32, false>)
+                          : (xm != nullptr ? conv3x3_kernel<T, NF, false, 32, true> : conv3x3_kernel<T, NF, false, 32, false>))
                    : (epi ? conv3x3_kernel<T, NF, true, C3F_TH> : conv3x3_kernel<T, NF, false, C3F_TH>);
   FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int tiles = B * ((H + TH - 1) / TH) * ((W + C3_TW - 1) / C3_TW);
@@ -693,6 +708,15 @@ int frl_conv3x3_bwd_data_fused(const void* dy, const void* y, int act, const flo
                                hipStream_t stream) {
   return c3_dispatch(dy, act != FRL_ACT_NONE ? y : nullptr, act, w, 9, (int64_t)Cin * 9, 1, nullptr, dx, B, H, W, Cout, Cin,
                      FRL_ACT_NONE, dtype, ws, ws_bytes, stream, add, sub_from, out2);
+}
+
+// dx = conv^T(dy .* act'(y)) .* out_act'(out_y): the gradient handed on to a backward pass through the activation that produced out_y
+// [B][H][W][Cin] (ReLU or sigmoid output at the same pixels) arrives there already masked.  out_act: FRL_ACT_RELU or FRL_ACT_SIGMOID.
+int frl_conv3x3_bwd_data_outmask(const void* dy, const void* y, int act, const float* w, void* dx, const void* out_y, int out_act, int B, int H,
+                                 int W, int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (out_y == nullptr || (out_act != FRL_ACT_RELU && out_act != FRL_ACT_SIGMOID)) return frl_fail(-2, "conv3x3_bwd_data_outmask: needs out_y and a ReLU / sigmoid out_act");
+  return c3_dispatch(dy, act != FRL_ACT_NONE ? y : nullptr, act, w, 9, (int64_t)Cin * 9, 1, nullptr, dx, B, H, W, Cout, Cin,
+                     FRL_ACT_NONE, dtype, ws, ws_bytes, stream, out_y, nullptr, nullptr, out_act == FRL_ACT_RELU ? 2 : 3);
 }
 
 size_t frl_conv3x3_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout) {

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void gate_blend_fwd_kernel(const T* __restrict
 template <typename T, int V>
 __global__ __launch_bounds__(256) void gate_blend_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ dgate_ext, const T* __restrict__ res,
                                                              const T* __restrict__ graw, float min_gate, T* __restrict__ dres,
-                                                             T* __restrict__ dgraw, int64_t nvec) {
+                                                             T* __restrict__ dgraw, int64_t nvec, int sigmoid_mask) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
     float d[V], r[V], g[V], x[V], o1[V], o2[V];
     Vec<T>::load(dout + i * V, d); Vec<T>::load(res + i * V, r); Vec<T>::load(graw + i * V, g);
@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256) void gate_blend_bwd_kernel(const T* __restrict
       const float ge = clamped ? min_gate : g[e];
       o1[e] = d[e] * ge;
       o2[e] = clamped ? 0.f : fmaf(d[e], r[e], x[e]);
+      if (sigmoid_mask) o2[e] *= g[e] * (1.f - g[e]);            // graw = sigmoid(.): hand on the gradient w.r.t. the pre-activation
     }
     Vec<T>::store(dres + i * V, o1);
     Vec<T>::store(dgraw + i * V, o2);
@@ -293,14 +294,20 @@ int frl_gate_blend_fwd(const void* smoothed, const void* residual, const void* g
   return frl_check_launch("gate_blend_fwd");
 }
 
-int frl_gate_blend_bwd(const void* dout, const void* dgate_ext, const void* residual, const void* gate_raw, float min_gate,
-                       void* d_residual, void* d_gate_raw, int64_t n, int dtype, hipStream_t stream) {
+// sigmoid_mask != 0: d_gate_raw is returned multiplied by gate_raw (1 - gate_raw) -- the derivative of the sigmoid that produced gate_raw
+// (gate_net of spatial.py:266-272) -- so that the convolution's backward calls take it without their own activation mask
+int frl_gate_blend_bwd_masked(const void* dout, const void* dgate_ext, const void* residual, const void* gate_raw, float min_gate,
+                              void* d_residual, void* d_gate_raw, int64_t n, int dtype, int sigmoid_mask, hipStream_t stream) {
   if (dtype == FRL_F32 && n % 4 == 0)
-    FRL_LAUNCH((gate_blend_bwd_kernel<float, 4>), dim3(ew_grid(n / 4)), dim3(256), 0, stream, (const float*)dout, (const float*)dgate_ext, (const float*)residual, (const float*)gate_raw, min_gate, (float*)d_residual, (float*)d_gate_raw, n / 4);
+    FRL_LAUNCH((gate_blend_bwd_kernel<float, 4>), dim3(ew_grid(n / 4)), dim3(256), 0, stream, (const float*)dout, (const float*)dgate_ext, (const float*)residual, (const float*)gate_raw, min_gate, (float*)d_residual, (float*)d_gate_raw, n / 4, sigmoid_mask);
   else if (dtype == FRL_BF16 && n % 8 == 0)
-    FRL_LAUNCH((gate_blend_bwd_kernel<bf16, 8>), dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16*)dout, (const bf16*)dgate_ext, (const bf16*)residual, (const bf16*)gate_raw, min_gate, (bf16*)d_residual, (bf16*)d_gate_raw, n / 8);
+    FRL_LAUNCH((gate_blend_bwd_kernel<bf16, 8>), dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16*)dout, (const bf16*)dgate_ext, (const bf16*)residual, (const bf16*)gate_raw, min_gate, (bf16*)d_residual, (bf16*)d_gate_raw, n / 8, sigmoid_mask);
   else return frl_fail(-2, "gate_blend: element count must be a multiple of the 16-byte vector width");
   return frl_check_launch("gate_blend_bwd");
+}
+int frl_gate_blend_bwd(const void* dout, const void* dgate_ext, const void* residual, const void* gate_raw, float min_gate,
+                       void* d_residual, void* d_gate_raw, int64_t n, int dtype, hipStream_t stream) {
+  return frl_gate_blend_bwd_masked(dout, dgate_ext, residual, gate_raw, min_gate, d_residual, d_gate_raw, n, dtype, 0, stream);
 }
 
 // tile [B][T][HWC] -> out [B][HWC] (mean over time)

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64 * SHB_NW, 2) void smooth_heads_bwd_kernel(const 
                                                                          const bf16* __restrict__ DS, const frag8* __restrict__ Wpk,
                                                                          const float* __restrict__ bA, const float* __restrict__ bB,
                                                                          bf16* __restrict__ DFEAT, bf16* __restrict__ U, bf16* __restrict__ AS,
-                                                                         float* __restrict__ slab, int B, int H, int W, int dil) {
+                                                                         float* __restrict__ slab, int B, int H, int W, int dil, int dfeat_relu) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   frag8* wB = reinterpret_cast<frag8*>(smem);
   frag8* wA = wB + SH_FR_B;
@@ -423,6 +423,12 @@ __global__ __launch_bounds__(64 * SHB_NW, 2) void smooth_heads_bwd_kernel(const 
           bf16x8 o0, o1;
 #pragma unroll
           for (int j = 0; j < 8; ++j) { o0[j] = (bf16)dfa[j >> 2][j & 3]; o1[j] = (bf16)dfa[2 + (j >> 2)][j & 3]; }
+          if (dfeat_relu) {                                       // feat = relu(.): hand the consumer d feat . [feat > 0] (its own mask pass is then not needed)
+            const bf16x8* fp = reinterpret_cast<const bf16x8*>(t_ft + prow * SHB_PF + 16 * kc);
+            const bf16x8 f0 = fp[0], f1 = fp[1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o0[j] = (float)f0[j] > 0.f ? o0[j] : zero; o1[j] = (float)f1[j] > 0.f ? o1[j] : zero; }
+          }
           bf16* fo = DFEAT + (int64_t)p * SH_HID + 16 * kc;
           *reinterpret_cast<bf16x8*>(fo) = o0;
           *reinterpret_cast<bf16x8*>(fo + 8) = o1;
@@ -671,9 +677,23 @@ int frl_smooth_heads_fwd(const void* x, const void* feat, const float* wa, const
 // (d smoothed - d residual); dx_add (optional) is added to dx (the direct path of x into the residual).  Outputs: dx, dfeat [P][64] bf16,
 // dwa [32][64], dba [32], dwb [256][64], dbb [256] f32.  scratch: u [P][256] + a_soft [P][32] bf16, caller-provided (exchange tensors
 // between the two launches): frl_smooth_heads_bwd_scratch_bytes.
+int frl_smooth_heads_bwd_masked(const void* d_smoothed, const void* x, const void* feat, const float* wa, const float* ba, const float* wb,
+                                const float* bb, const void* dx_add, void* dx, void* dfeat, float* dwa, float* dba, float* dwb, float* dbb,
+                                void* scratch, size_t scratch_bytes, int B, int H, int W, int dil, int dfeat_relu, void* ws, size_t ws_bytes,
+                                hipStream_t stream);
 int frl_smooth_heads_bwd(const void* d_smoothed, const void* x, const void* feat, const float* wa, const float* ba, const float* wb,
                          const float* bb, const void* dx_add, void* dx, void* dfeat, float* dwa, float* dba, float* dwb, float* dbb,
                          void* scratch, size_t scratch_bytes, int B, int H, int W, int dil, void* ws, size_t ws_bytes, hipStream_t stream) {
+  return frl_smooth_heads_bwd_masked(d_smoothed, x, feat, wa, ba, wb, bb, dx_add, dx, dfeat, dwa, dba, dwb, dbb, scratch, scratch_bytes, B, H, W, dil, 0,
+                                     ws, ws_bytes, stream);
+}
+
+// The same with dfeat_relu != 0: dfeat is returned already multiplied by [feat > 0] (feat is the output of a ReLU convolution, mix_backbone
+// of spatial.py:258-261), so that convolution's backward-data / backward-weight calls take it without their own activation mask.
+int frl_smooth_heads_bwd_masked(const void* d_smoothed, const void* x, const void* feat, const float* wa, const float* ba, const float* wb,
+                                const float* bb, const void* dx_add, void* dx, void* dfeat, float* dwa, float* dba, float* dwb, float* dbb,
+                                void* scratch, size_t scratch_bytes, int B, int H, int W, int dil, int dfeat_relu, void* ws, size_t ws_bytes,
+                                hipStream_t stream) {
   const int64_t npix = (int64_t)B * H * W;
   if (npix <= 0) return frl_fail(-2, "smooth_heads_bwd: empty input");
   if (npix * SH_NB >= (int64_t)1 << 31) return frl_fail(-2, "smooth_heads_bwd: too many pixels for 32-bit element offsets");
@@ -692,7 +712,7 @@ int frl_smooth_heads_bwd(const void* d_smoothed, const void* x, const void* feat
                      (size_t)SHB_R * (SHB_PLB + SHB_PF) * sizeof(bf16);
   FRL_HIP(hipFuncSetAttribute((const void*)smooth_heads_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   FRL_LAUNCH(smooth_heads_bwd_kernel, dim3((unsigned)g), dim3(64 * SHB_NW), lds, stream, (const bf16*)x, (const bf16*)feat, (const bf16*)d_smoothed,
-             pk, ba, bb, (bf16*)dfeat, u, as, slab, B, H, W, dil);
+             pk, ba, bb, (bf16*)dfeat, u, as, slab, B, H, W, dil, dfeat_relu);
   launch_slab_reduce_deferrable<float, ShEpi>((const float*)slab, (int)g, (int64_t)SHB_SLAB, ShEpi{dwb, dwa, dbb, dba, SH_NB, SH_NA, SH_HID}, stream);
   // kernel 2: tiled through the LDS when full-width bands of TH rows (+ dil halo rows each side) make whole waves and fit, else gathers
   int TH = 0;

@@ -886,4 +886,38 @@ int frl_tcn_hot_bwd(const void* x, const void* drop_mask, const void* dy, const 
   return frl_check_launch("tcn_hot_bwd");
 }
 
+// The last block of the phase encoder together with the backward-data of the 1x1 phase head behind it (representation.py:169): dh
+// [B][5][HW][Ch] bf16 is the head's output gradient, head_w [Ch][64] float32; dy = dh head_w is formed inside the kernel (matrix cores) and
+// never written.  Same outputs as frl_tcn_hot_bwd.  Needs the two-subgroup kernel (no mask, HW % 64 == 0, dilation 4, dx != NULL).
+int frl_tcn_hot_bwd_head_supported(int64_t npix, int HW, int Ch) {
+  return (th_bwd4_supported(npix, HW) && !g_th_force_bwd2 && g_th_bwd_variant == 4 && Ch >= 4 && Ch <= 16 && (Ch & 3) == 0) ? 1 : 0;
+}
+size_t frl_tcn_hot_bwd_head_workspace_bytes(int64_t npix) { return frl_tcn_hot_bwd_workspace_bytes(npix) + 4096; }
+int frl_tcn_hot_bwd_head(const void* x, const void* dh, const float* head_w, int Ch, const float* conv_w, const float* conv_b, const float* gn_w,
+                         const float* gn_b, const float* gate_w, const float* gate_b, void* dx, float* d_conv_w, float* d_conv_b, float* d_gn_w,
+                         float* d_gn_b, float* d_gate_w, float* d_gate_b, int64_t npix, int HW, int dilation, float eps, void* ws, size_t ws_bytes,
+                         hipStream_t stream) {
+  if (npix <= 0 || HW <= 0) return frl_fail(-2, "tcn_hot_bwd_head: empty input");
+  if (!frl_tcn_hot_bwd_head_supported(npix, HW, Ch)) return frl_fail(-2, "tcn_hot_bwd_head: unsupported shape (HW % 64, head width 4..16 in fours)");
+  if (ws == nullptr || ws_bytes < frl_tcn_hot_bwd_head_workspace_bytes(npix)) return frl_fail(-4, "tcn_hot_bwd_head: workspace too small");
+  const unsigned grid = th_bwd_grid(npix);
+  float* slab = (float*)ws;
+  char* wpk = reinterpret_cast<char*>(ws) + (((size_t)grid * TH_SLAB * sizeof(float) + 255) / 256) * 256;
+  const frag8* pk = th_packed(conv_w, gate_w, reinterpret_cast<frag8*>(wpk), stream);
+  const frag8* whp;
+  {                                                                  // W_h^T as an A-operand image: rows = the 64 block channels, contraction = Ch (padded to 32)
+    FrlPackJob job = frl_pack_job_pw(head_w, 0, FRL_BF16, 1, 64, Ch, 4, 1, 64);
+    bool hit = false;
+    frag8* img = reinterpret_cast<frag8*>(wpk + TH_PACK_BYTES);
+    if (void* c = frl_pack_cached(&job, 1, (size_t)4 * 64 * sizeof(frag8), &hit)) img = (frag8*)c;
+    if (!hit) FRL_LAUNCH((pack_weights_kernel<bf16, 1>), dim3(1), dim3(256), 0, stream, img, head_w, 64, Ch, 4, (int64_t)1, (int64_t)64);
+    whp = img;
+  }
+  const int rc = th_bwd4_launch(dilation, x, dh, pk, conv_b, gn_w, gn_b, gate_b, dx, slab, grid, npix, HW, eps, stream, whp, Ch);
+  if (rc) return rc;
+  launch_slab_reduce_deferrable<float, ThEpi>((const float*)slab, (int)grid, (int64_t)TH_SLAB, ThEpi{d_conv_w, d_gate_w, d_conv_b, d_gate_b, d_gn_w, d_gn_b},
+                                   stream);
+  return frl_check_launch("tcn_hot_bwd_head");
+}
+
 }  // extern "C"

@@ -33,6 +33,7 @@
 #define B4_TILE (B4_GACC + 2048 + 1024)        // 36864
 #define B4_SG (3 * B4_TB)                      // 61440: the three tile buffers of one subgroup
 #define B4_LDS (B4_TILE + 2 * B4_SG)           // 159744 <= 160 KiB
+#define B4_HEADW B4_LDS                        // HEAD instantiation: 4 KB image of W_h^T behind the tile buffers (163840 = the whole LDS)
 // Subgroup 0's share of the workgroup's tiles, in 32nds.  The split is static (dynamic hand-out would make the float32 summation order of
 // the weight gradients depend on timing), and it is NOT half: when both waves of a SIMD are ready the sequencer issues from the older
 // one, so subgroup 0 (waves 0-3) runs a tile in ~22 k cycles and subgroup 1 in ~31 k while both are busy (s_setprio on subgroup 1 does
@@ -127,11 +128,16 @@ __device__ int b4_knob[2] = {0, 16};           // wave priority experiment, subg
 
 // WANT_DX = false: the block's input is data (the first block of the phase path reads the tile itself): the conv^T GEMM, the residual
 // gradient and the dx store are compiled out.
-template <int DIL, bool WANT_DX>
+// HEAD = true (the last block of the phase encoder): DY is not the block's output gradient but dh [B][5][HW][Chd], the gradient of the 1x1
+// phase head's output (representation.py:169), and dy = dh W_h is formed on the matrix cores from a 4 KB image of W_h^T in LDS (Whp:
+// [4 row blocks][64 lanes] fragments, contraction width padded to 32): the head's backward-data launch and the round trip of dy
+// (168 MB written, 168 MB read) disappear; dy stays float32 instead of being rounded to bf16 on the way.
+template <int DIL, bool WANT_DX, bool HEAD>
 __global__ __launch_bounds__(512, 2) void tcn_hot_bwd4_kernel(const bf16* __restrict__ X, const bf16* __restrict__ DY, const frag8* __restrict__ Wpk,
                                                               const float* __restrict__ bc, const float* __restrict__ gn_w,
                                                               const float* __restrict__ gn_b, const float* __restrict__ bg, bf16* __restrict__ DX,
-                                                              float* __restrict__ slab, int ntile, int HW, float eps) {
+                                                              float* __restrict__ slab, int ntile, int HW, float eps,
+                                                              const frag8* __restrict__ Whp, int Chd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tab = reinterpret_cast<float*>(smem + B4_TAB);
   float* gacc_lds = reinterpret_cast<float*>(smem + B4_GACC);
@@ -195,6 +201,31 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd4_kernel(const bf16* __rest
     }
   };
 
+  // ---- dy of one tile -> registers.  HEAD: the lane's slice of the dh row instead (B operand of dy = W_h^T dh: channels 8 kc .. 8 kc + 7 of
+  // its pixel, zero beyond Chd; rows are Chd * 2 bytes apart, so the two 8-byte halves are loaded separately)
+  auto dy_load = [&](int wt, frag8 (&dst)[TH_T]) {
+    unsigned k2_ = pk2;
+    asm volatile("" : "+v"(k2_));
+    if constexpr (!HEAD) {
+      const bf16* dyb = DY + tile_base(wt);
+      const unsigned le = (k2_ >> 10) & 0xfffu;
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t) dst[t] = *reinterpret_cast<const frag8*>(dyb + t * tstride + le);
+    } else {
+      const int pxl = (int)((k2_ >> 22) & 15u), kcl = (int)(k2_ >> 26);
+      const unsigned b = (unsigned)wt / tps;
+      const bf16* dhb = DY + ((int64_t)wt * 32 + (int64_t)b * (TH_T - 1) * HW + q * 16 + pxl) * Chd + 8 * kcl;
+      const bool lo_ok = 8 * kcl < Chd, hi_ok = 8 * kcl + 4 < Chd;
+      const bf16x4 z4 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+#pragma unroll
+      for (int t = 0; t < TH_T; ++t) {
+        const bf16* p = dhb + (int64_t)t * HW * Chd;
+        const bf16x4 lo = lo_ok ? *reinterpret_cast<const bf16x4*>(p) : z4;
+        const bf16x4 hi = hi_ok ? *reinterpret_cast<const bf16x4*>(p + 4) : z4;
+        dst[t] = b4_join(lo, hi);
+      }
+    }
+  };
   int xoff = B4_TILE + sg * B4_SG, noff = xoff + B4_TB;
   const int aoff = xoff + 2 * B4_TB;
   // the workgroup's tiles are blockIdx.x + i gridDim.x; subgroup 0 takes the first B4_SHARE0 / 32 of them, subgroup 1 the rest
@@ -213,12 +244,9 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd4_kernel(const bf16* __rest
   const int wt0 = (int)blockIdx.x + i_beg * wstep, wt_end = (int)blockIdx.x + i_end * wstep;   // this subgroup's tiles: wt0, wt0 + wstep, ... < wt_end
   dma_tile(wt0 < ntile ? wt0 : ntile - 1, xoff);
   frag8 dyn[TH_T];
-  {
-    const bf16* dyb = DY + tile_base(wt0 < ntile ? wt0 : ntile - 1);
-#pragma unroll
-    for (int t = 0; t < TH_T; ++t) dyn[t] = *reinterpret_cast<const frag8*>(dyb + t * tstride + lane_el);
-  }
+  dy_load(wt0 < ntile ? wt0 : ntile - 1, dyn);
   copy_frags_lds<bf16>(reinterpret_cast<frag8*>(smem + B4_W), Wpk, 32 * 64, tid, 512);
+  if constexpr (HEAD) copy_frags_lds<bf16>(reinterpret_cast<frag8*>(smem + B4_HEADW), Whp, 4 * 64, tid, 512);
   gacc_lds[tid] = 0.f;                                             // [8 waves][4 kc][8 d gamma | 8 d beta]
   if (tid < 2) *reinterpret_cast<unsigned*>(smem + B4_BAR + 128 * tid) = 0u;
   if (tid < 64) {
@@ -332,17 +360,19 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd4_kernel(const bf16* __rest
       for (int t = 0; t < TH_T; ++t) {
         const frag8 nt0 = b4_ld(smem, noff + t * B4_TT + fo), nt1 = b4_ld(smem, noff + t * B4_TT + (fo ^ 16));
         const frag8 xo = b4_ld(smem, xoff + t * B4_TT + oo);   // residual path: x of this lane's 8 channels
-        f32x4 gacc[2];
+        f32x4 gacc[2], dyf[2];
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm) {
           gacc[mm] = mfma16(wg[mm][0], nt0, f32x4{0.f, 0.f, 0.f, 0.f});
           gacc[mm] = mfma16(wg[mm][1], nt1, gacc[mm]);
+          if constexpr (HEAD) dyf[mm] = mfma16(b4_ld(smem, B4_HEADW + ((2 * h + mm) * 64) * 16 + (px_ + 16 * kc_) * 16), dyo[t], f32x4{0.f, 0.f, 0.f, 0.f});
         }
+        (void)dyf;
         float dgp[8], dygv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float n = fmaf(xh[t][e >> 2][e & 3], gw[e], gb[e]);
-          const float dyv = (float)dyo[t][e];
+          const float dyv = HEAD ? dyf[e >> 2][e & 3] : (float)dyo[t][e];
           const float g = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(gacc[e >> 2][e & 3], -1.44269504088896f, tnbg[e])));
           const float o = fmaxf(n, 0.f);
           const float res = (float)xo[e];
@@ -450,12 +480,7 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd4_kernel(const bf16* __rest
     // ---------------- the next tile's x -> N buffer (LDS-DMA), its dy -> registers; publish dconv[t] ----------------
     const int wtn = wt + wstep;
     if (wtn < wt_end) dma_tile(wtn, noff);
-    {                                                              // (unconditional, from a clamped tile: dyn must not stay live across the tile)
-      const bf16* dyb = DY + tile_base(wtn < wt_end ? wtn : wt);
-      B4_ADDR();
-#pragma unroll
-      for (int t = 0; t < TH_T; ++t) dyn[t] = *reinterpret_cast<const frag8*>(dyb + t * tstride + le_);
-    }
+    dy_load(wtn < wt_end ? wtn : wt, dyn);                           // (unconditional, from a clamped tile: dyn must not stay live across the tile)
     {
       B4_ADDR();
 #pragma unroll
@@ -470,11 +495,7 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd4_kernel(const bf16* __rest
       // dres = dy - dy g: dy of this tile is fetched a second time (an L2 hit: the same compute unit read it for S2) instead of being
       // carried in 20 registers from S2 to here; the loads land behind the conv^T GEMM
       frag8 dyr[TH_T];
-      {
-        const bf16* dyb = DY + tile_base(wt);
-#pragma unroll
-        for (int t = 0; t < TH_T; ++t) dyr[t] = *reinterpret_cast<const frag8*>(dyb + t * tstride + le_);
-      }
+      dy_load(wt, dyr);
       f32x4 dxa[TH_T][2];
 #pragma unroll
       for (int t = 0; t < TH_T; ++t)
@@ -498,8 +519,12 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd4_kernel(const bf16* __rest
 #pragma unroll
       for (int t = 0; t < TH_T; ++t) {
         float y[8];
+        if constexpr (HEAD) {                                        // dy = W_h^T dh once more (two MFMAs) instead of a second read of 128 bytes
 #pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] = dxa[t][e >> 2][e & 3] + ((float)dyr[t][e] - (float)dyg8[t][e]);
+          for (int mm = 0; mm < 2; ++mm) dxa[t][mm] = mfma16(b4_ld(smem, B4_HEADW + ((2 * h + mm) * 64) * 16 + (px_ + 16 * kc_) * 16), dyr[t], dxa[t][mm]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = dxa[t][e >> 2][e & 3] + ((HEAD ? 0.f : (float)dyr[t][e]) - (float)dyg8[t][e]);
         *reinterpret_cast<frag8*>(dxb + t * tstride + le_) = th_pack8(y);
       }
     }
@@ -593,19 +618,30 @@ template <int DIL>
 static void b4_launch(const void* x, const void* dy, const frag8* pk, const float* bc, const float* gw, const float* gb, const float* bg, void* dx,
                       float* slab, unsigned grid, int ntile, int HW, float eps, hipStream_t st) {
   if (dx != nullptr) {
-    auto kern = tcn_hot_bwd4_kernel<DIL, true>;
+    auto kern = tcn_hot_bwd4_kernel<DIL, true, false>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B4_LDS);
-    FRL_LAUNCH_AS("tcn_hot_bwd4_kernel", kern, dim3(grid), dim3(512), B4_LDS, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx, slab, ntile, HW, eps);
+    FRL_LAUNCH_AS("tcn_hot_bwd4_kernel", kern, dim3(grid), dim3(512), B4_LDS, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx, slab, ntile, HW, eps,
+                  (const frag8*)nullptr, 0);
   } else {
-    auto kern = tcn_hot_bwd4_kernel<DIL, false>;
+    auto kern = tcn_hot_bwd4_kernel<DIL, false, false>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B4_LDS);
-    FRL_LAUNCH_AS("tcn_hot_bwd4_nodx_kernel", kern, dim3(grid), dim3(512), B4_LDS, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)nullptr, slab, ntile, HW, eps);
+    FRL_LAUNCH_AS("tcn_hot_bwd4_nodx_kernel", kern, dim3(grid), dim3(512), B4_LDS, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)nullptr, slab, ntile, HW, eps,
+                  (const frag8*)nullptr, 0);
   }
 }
 
+// whp != NULL: `dy` is dh [B][5][HW][chd], the output gradient of the 1x1 head behind this block (dilation 4, dx wanted): tcn_hot_bwd4_kernel<4, true, true>
 int th_bwd4_launch(int dilation, const void* x, const void* dy, const frag8* pk, const float* bc, const float* gw, const float* gb, const float* bg,
-                   void* dx, float* slab, unsigned grid, int64_t npix, int HW, float eps, hipStream_t st) {
+                   void* dx, float* slab, unsigned grid, int64_t npix, int HW, float eps, hipStream_t st, const frag8* whp, int chd) {
   const int ntile = (int)(npix / 32);
+  if (whp != nullptr) {
+    if (dilation != 4 || dx == nullptr) return frl_fail(-2, "tcn_hot_bwd_head: the head variant serves the last block (dilation 4, dx wanted)");
+    auto kern = tcn_hot_bwd4_kernel<4, true, true>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B4_LDS + 4096));
+    FRL_LAUNCH_AS("tcn_hot_bwd4_head_kernel", kern, dim3(grid), dim3(512), B4_LDS + 4096, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx, slab, ntile, HW,
+                  eps, whp, chd);
+    return 0;
+  }
   if (dilation == 1) b4_launch<1>(x, dy, pk, bc, gw, gb, bg, dx, slab, grid, ntile, HW, eps, st);
   else if (dilation == 2) b4_launch<2>(x, dy, pk, bc, gw, gb, bg, dx, slab, grid, ntile, HW, eps, st);
   else if (dilation == 4) b4_launch<4>(x, dy, pk, bc, gw, gb, bg, dx, slab, grid, ntile, HW, eps, st);

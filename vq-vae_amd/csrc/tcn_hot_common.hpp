@@ -40,4 +40,4 @@ int th_bwd3_launch(int dilation, const void* x, const void* dy, const frag8* pk,
 // tcn_hot_bwd4.hip: the same backward cut into two independent 4-wave subgroups per workgroup (32-pixel tiles); same conditions and slabs
 bool th_bwd4_supported(int64_t npix, int HW);
 int th_bwd4_launch(int dilation, const void* x, const void* dy, const frag8* pk, const float* bc, const float* gw, const float* gb, const float* bg,
-                   void* dx, float* slab, unsigned grid, int64_t npix, int HW, float eps, hipStream_t st);
+                   void* dx, float* slab, unsigned grid, int64_t npix, int HW, float eps, hipStream_t st, const frag8* whp = nullptr, int chd = 0);

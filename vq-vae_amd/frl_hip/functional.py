@@ -226,22 +226,33 @@ class SpatialSmoothFn(Function):
         x, g, feat, a_soft, b_soft, res, g1, gate_raw, w_mb, w_a, w_b, w_g0, w_g2, b_a, b_b = ctx.saved_tensors
         rank, dil, min_gate = ctx.cfg
         dout = torch.zeros_like(res) if dout is None else _c(dout)
-        dres, dgraw = ops.gate_blend_bwd(dout, _c(dgate), res, gate_raw, min_gate)
-        dg1 = ops.conv3x3_bwd_data(dgraw, w_g2, gate_raw, ACT_SIGMOID)
-        dw_g2, db_g2 = ops.conv3x3_bwd_weight(dgraw, g1, gate_raw, ACT_SIGMOID)
+        # Activation masks of the three 3x3 convolutions are folded into the kernels that PRODUCE their incoming gradients (gate-blend backward:
+        # sigmoid' of the gate; epilogue of the gate net's second backward-data: relu' of g1; mixing-heads backward: relu' of feat), so the six
+        # 3x3 backward calls run without a mask pass over their input (16-35 us per backward-data, 6-15 us per weight gradient)
+        pre = ops.fusion_enabled("premask")
+        dres, dgraw = ops.gate_blend_bwd(dout, _c(dgate), res, gate_raw, min_gate, sigmoid_mask=pre)
+        a2, y2 = (ACT_NONE, None) if pre else (ACT_SIGMOID, gate_raw)
+        if pre:
+            dg1 = ops.conv3x3_bwd_data(dgraw, w_g2, None, ACT_NONE, out_y=g1, out_act=ACT_RELU)
+        else:
+            dg1 = ops.conv3x3_bwd_data(dgraw, w_g2, gate_raw, ACT_SIGMOID)
+        dw_g2, db_g2 = ops.conv3x3_bwd_weight(dgraw, g1, y2, a2)
+        a0, y0 = (ACT_NONE, None) if pre else (ACT_RELU, g1)
         # residual: blend term + gate-net term in one store; d(smoothed) - d(residual) (residual = x - smoothed) as the second output
-        dres_tot, d_tot = ops.conv3x3_bwd_data(dg1, w_g0, g1, ACT_RELU, add=dres, sub_from=dout)
-        dw_g0, db_g0 = ops.conv3x3_bwd_weight(dg1, res, g1, ACT_RELU)
+        dres_tot, d_tot = ops.conv3x3_bwd_data(dg1, w_g0, y0, a0, add=dres, sub_from=dout)
+        dw_g0, db_g0 = ops.conv3x3_bwd_weight(dg1, res, y0, a0)
+        pre_f = pre and ctx.fused_heads
         if ctx.fused_heads:
-            dx, dfeat, dw_a, db_a, dw_b, db_b = ops.smooth_heads_bwd(d_tot, x, feat, w_a, b_a, w_b, b_b, dil, dx_add=dres_tot)
+            dx, dfeat, dw_a, db_a, dw_b, db_b = ops.smooth_heads_bwd(d_tot, x, feat, w_a, b_a, w_b, b_b, dil, dx_add=dres_tot, dfeat_relu=pre_f)
         else:
             dx, da, db = ops.edge_smooth_bwd(d_tot, x, a_soft, b_soft, rank, dil, dx_add=dres_tot)
             dfeat = ops.conv1x1_bwd_data(db, w_b, None, ACT_NONE, add=ops.conv1x1_bwd_data(da, w_a, None, ACT_NONE))
             dw_a, db_a = ops.conv1x1_bwd_weight(da, feat, None, ACT_NONE, want_bias=ctx.has_bias[1])
             dw_b, db_b = ops.conv1x1_bwd_weight(db, feat, None, ACT_NONE, want_bias=ctx.has_bias[2])
-        dw_mb, db_mb = ops.conv3x3_bwd_weight(dfeat, g, feat, ACT_RELU)
+        af, yf = (ACT_NONE, None) if pre_f else (ACT_RELU, feat)
+        dw_mb, db_mb = ops.conv3x3_bwd_weight(dfeat, g, yf, af)
         if ctx.needs_input_grad[0]:
-            dx = ops.sobel_bwd(ops.conv3x3_bwd_data(dfeat, w_mb, feat, ACT_RELU), add=dx)
+            dx = ops.sobel_bwd(ops.conv3x3_bwd_data(dfeat, w_mb, yf, af), add=dx)
         else:
             dx = None
         hb = ctx.has_bias
@@ -295,12 +306,17 @@ class TcnChainHeadFn(Function):
         groups, eps = ctx.cfg
         dh = _c(dh)
         w2 = head_w.reshape(head_w.shape[0], head_w.shape[1])
-        dy = ops.conv1x1_bwd_data(dh, w2, None, ACT_NONE)
         dw_h, db_h = ops.conv1x1_bwd_weight(dh, y3, None, ACT_NONE, want_bias=True)
+        # the head's backward-data rides inside the last block's backward kernel where that kernel applies (dy = dh W_h never reaches HBM)
+        head_in_kernel = groups == 8 and ops.tcn_block_bwd_head_supported(y2, dh, w2, 4)
+        dy = None if head_in_kernel else ops.conv1x1_bwd_data(dh, w2, None, ACT_NONE)
         grads = [None] * 18
         for i, (xin, dil) in reversed(list(enumerate(zip((x, y1, y2), (1, 2, 4))))):
             cw, cb, gw, gb, tw, tb = params[6 * i:6 * i + 6]
-            g = ops.tcn_block_bwd(xin, dy, cw, cb, gw, gb, tw, tb, None, None, dil, groups, eps, want_dx=(i > 0 or ctx.needs_input_grad[0]))
+            if i == 2 and head_in_kernel:
+                g = ops.tcn_block_bwd_head(xin, dh, w2, cw, cb, gw, gb, tw, tb, dil, eps)
+            else:
+                g = ops.tcn_block_bwd(xin, dy, cw, cb, gw, gb, tw, tb, None, None, dil, groups, eps, want_dx=(i > 0 or ctx.needs_input_grad[0]))
             grads[6 * i:6 * i + 6] = [g["conv_w"], g["conv_b"], g["gn_w"], g["gn_b"], g["gate_w"], g["gate_b"]]
             dy = g["dx"]
         return (dy if ctx.needs_input_grad[0] else None,) + tuple(grads) + (dw_h.reshape(head_w.shape), db_h, None, None)

@@ -586,11 +586,12 @@ def gate_blend_fwd(smoothed, residual, gate_raw, min_gate: float):
 
 
 @_timed("gate_blend_bwd")
-def gate_blend_bwd(dout, dgate_ext, residual, gate_raw, min_gate: float):
+def gate_blend_bwd(dout, dgate_ext, residual, gate_raw, min_gate: float, sigmoid_mask: bool = False):
+    """-> (d residual, d gate_raw); sigmoid_mask: d gate_raw comes back multiplied by gate_raw (1 - gate_raw) (gradient w.r.t. the pre-activation)."""
     dres = torch.empty_like(dout)
     dgraw = torch.empty_like(dout)
-    check(_lib.load().frl_gate_blend_bwd(_p(dout), _p(dgate_ext), _p(residual), _p(gate_raw), float(min_gate), _p(dres),
-                                         _p(dgraw), dout.numel(), _dt(dout), _stream()), "frl_gate_blend_bwd")
+    check(_lib.load().frl_gate_blend_bwd_masked(_p(dout), _p(dgate_ext), _p(residual), _p(gate_raw), float(min_gate), _p(dres),
+                                                _p(dgraw), dout.numel(), _dt(dout), int(sigmoid_mask), _stream()), "frl_gate_blend_bwd_masked")
     return dres, dgraw
 
 
@@ -752,13 +753,21 @@ def conv3x3_fwd_gate_blend(x, w, bias, smoothed, residual):
 
 
 @_timed("conv3x3_bwd_data")
-def conv3x3_bwd_data(dy, w, y=None, act: int = ACT_NONE, add=None, sub_from=None):
-    """dx = conv3x3^T(dy .* act'(y)) (+ add).  With sub_from the call returns (dx, sub_from - dx): both extras ride in the epilogue."""
+def conv3x3_bwd_data(dy, w, y=None, act: int = ACT_NONE, add=None, sub_from=None, out_y=None, out_act: int = ACT_NONE):
+    """dx = conv3x3^T(dy .* act'(y)) (+ add).  With sub_from the call returns (dx, sub_from - dx): both extras ride in the epilogue.
+    out_y / out_act (instead of add / sub_from): dx .* out_act'(out_y) -- the gradient arrives at the next backward step already masked."""
     b, h, wd, cout = dy.shape
     cin = w.shape[1]
     dx = torch.empty(b, h, wd, cin, dtype=dy.dtype, device=dy.device)
     lib = _lib.load()
     ws = workspace(lib.frl_conv_workspace_bytes(cin, cout, 9), dy.device)
+    if out_y is not None:
+        if add is not None or sub_from is not None:
+            raise ValueError("conv3x3_bwd_data: out_y does not combine with add / sub_from")
+        _chk_like(out_y, dx, "conv3x3_bwd_data.out_y")
+        check(lib.frl_conv3x3_bwd_data_outmask(_p(dy), _p(y), act, _p(_f32(w, "w")), _p(dx), _p(out_y), out_act, b, h, wd, cin, cout, _dt(dy),
+                                               _p(ws), ws.numel(), _stream()), "frl_conv3x3_bwd_data_outmask")
+        return dx
     if add is not None or sub_from is not None:
         out2 = None
         if add is not None:
@@ -866,9 +875,9 @@ def smooth_heads_fwd(x, feat, wa, ba, wb, bb, coarse_dilation: int):
 
 
 @_timed("smooth_heads_bwd")
-def smooth_heads_bwd(d_smoothed, x, feat, wa, ba, wb, bb, coarse_dilation: int, dx_add: Optional[torch.Tensor] = None):
+def smooth_heads_bwd(d_smoothed, x, feat, wa, ba, wb, bb, coarse_dilation: int, dx_add: Optional[torch.Tensor] = None, dfeat_relu: bool = False):
     """-> (dx, dfeat [B,H,W,64] bf16, dwa, dba, dwb, dbb f32).  d_smoothed: gradient w.r.t. `smoothed` with the residual path folded in
-    (d smoothed - d residual); dx_add: added to dx inside the kernel's store."""
+    (d smoothed - d residual); dx_add: added to dx inside the kernel's store; dfeat_relu: dfeat comes back multiplied by [feat > 0]."""
     b, h, w, c = x.shape
     for t, n in ((d_smoothed, "d_smoothed"), (feat, "feat")):
         _chk_like(t, x, f"smooth_heads_bwd.{n}")
@@ -881,9 +890,10 @@ def smooth_heads_bwd(d_smoothed, x, feat, wa, ba, wb, bb, coarse_dilation: int, 
     dx, dfeat = torch.empty_like(x), torch.empty_like(feat)
     dwa, dwb = torch.empty(wa.shape, dtype=torch.float32, device=x.device), torch.empty(wb.shape, dtype=torch.float32, device=x.device)
     dba, dbb = torch.empty_like(ba), torch.empty_like(bb)
-    check(lib.frl_smooth_heads_bwd(_p(d_smoothed), _p(x), _p(feat), _p(_f32(wa, "wa")), _p(_f32(ba, "ba")), _p(_f32(wb, "wb")), _p(_f32(bb, "bb")),
-                                   _p(dx_add), _p(dx), _p(dfeat), _p(dwa), _p(dba), _p(dwb), _p(dbb), _p(scratch), scratch.numel(),
-                                   b, h, w, coarse_dilation, _p(ws), ws.numel(), _stream()), "frl_smooth_heads_bwd")
+    check(lib.frl_smooth_heads_bwd_masked(_p(d_smoothed), _p(x), _p(feat), _p(_f32(wa, "wa")), _p(_f32(ba, "ba")), _p(_f32(wb, "wb")),
+                                          _p(_f32(bb, "bb")), _p(dx_add), _p(dx), _p(dfeat), _p(dwa), _p(dba), _p(dwb), _p(dbb), _p(scratch),
+                                          scratch.numel(), b, h, w, coarse_dilation, int(dfeat_relu), _p(ws), ws.numel(), _stream()),
+          "frl_smooth_heads_bwd_masked")
     return dx, dfeat, dwa, dba, dwb, dbb
 
 
@@ -964,6 +974,40 @@ def tcn_chain_fwd(x, blocks, head_w, head_b, eps: float = 1e-5):
 
 
 @_timed("tcn_block_bwd")
+def tcn_block_bwd_head_supported(x, dh, head_w, dilation: int) -> bool:
+    """True when the last phase block's backward can take the head's output gradient dh directly (csrc/tcn_hot_bwd4.hip, HEAD variant)."""
+    b, t, cin = x.shape[0], x.shape[1], x.shape[-1]
+    hw = x.numel() // (b * t * cin)
+    lib = _lib.load()
+    return bool(fusion_enabled("headbwd") and dilation == 4 and x.dtype == torch.bfloat16 and dh.dtype == torch.bfloat16 and
+                lib.frl_tcn_hot_supported(t, cin, cin, 8, dilation, 0, _dt(x)) and
+                lib.frl_tcn_hot_bwd_head_supported(b * hw, hw, int(head_w.shape[0])))
+
+
+@_timed("tcn_block_bwd")
+def tcn_block_bwd_head(x, dh, head_w, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, dilation: int, eps: float = 1e-5):
+    """Backward of the last hot block fed with dh [B,T,HW..,Ch] (gradient of the 1x1 phase head's output) and head_w [Ch,64]: dy = dh head_w is
+    formed inside the kernel.  Returns the dict of tcn_block_bwd."""
+    b, t, cin = x.shape[0], x.shape[1], x.shape[-1]
+    cout = conv_w.shape[0]
+    hw = x.numel() // (b * t * cin)
+    npix = b * hw
+    ch = int(head_w.shape[0])
+    _chk_rows(dh, ch, "tcn_block_bwd_head.dh")
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    g = {k: torch.empty_like(v, dtype=torch.float32) for k, v in
+         dict(conv_w=conv_w, conv_b=conv_b, gn_w=gn_w, gn_b=gn_b, gate_w=gate_w, gate_b=gate_b).items()}
+    ws = workspace(lib.frl_tcn_hot_bwd_head_workspace_bytes(npix), x.device)
+    with span("tcn_block_bwd.main"):
+        check(lib.frl_tcn_hot_bwd_head(_p(x), _p(dh), _p(_f32(head_w.reshape(ch, cin), "head_w")), ch, _p(conv_w), _p(conv_b), _p(gn_w), _p(gn_b),
+                                       _p(gate_w.reshape(cout, cout)), _p(gate_b), _p(dx), _p(g["conv_w"]), _p(g["conv_b"]), _p(g["gn_w"]),
+                                       _p(g["gn_b"]), _p(g["gate_w"]), _p(g["gate_b"]), npix, hw, dilation, float(eps), _p(ws), ws.numel(),
+                                       _stream()), "frl_tcn_hot_bwd_head")
+    g["dx"] = dx
+    return g
+
+
 def tcn_block_bwd(x, dy, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b, proj_w, proj_b, dilation: int, groups: int,
                   eps: float = 1e-5, allow_fused: bool = True, allow_hot: bool = True, drop_mask=None, want_dx: bool = True):
     """Returns dict(dx, conv_w, conv_b, gn_w, gn_b, gate_w, gate_b[, proj_w, proj_b]) gradients.  want_dx=False (the block's input
