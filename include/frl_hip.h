@@ -274,6 +274,7 @@ int frl_tcn_hot_bwd(const void* x, const void* drop_mask, const void* dy, const 
  * followed by the 1x1 phase head (representation.py:169,362-366): x [B][5][HW][64] -> y1, y2, y3 (the blocks' outputs, kept for the
  * backward) and h [B][5][HW][Ch] = head_w y3 + head_b, Ch in {4, 8, 12, 16}.  conv_w .. gate_b: arrays of three pointers (block 0, 1, 2). */
 size_t frl_tcn_chain_fwd_workspace_bytes(void);
+int frl_tcn_chain_static_tiles(int on);   /* A/B hook: 1 = fixed tile sequence per wave, 0 (default) = tiles handed out by an LDS counter; returns the previous setting */
 int frl_tcn_chain_fwd(const void* x, const float* const* conv_w, const float* const* conv_b, const float* const* gn_w,
                       const float* const* gn_b, const float* const* gate_w, const float* const* gate_b, const float* head_w,
                       const float* head_b, void* y1, void* y2, void* y3, void* h, int64_t npix, int HW, int Ch, float eps, void* ws,

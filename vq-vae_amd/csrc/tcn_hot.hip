@@ -254,7 +254,7 @@ struct ThChainArgs {
 };
 
 #define THC_IMG (32 * 64)                                          // fragments of one block's forward image (conv taps + gate)
-__global__ __launch_bounds__(512, 2) void tcn_chain_fwd_kernel(const bf16* __restrict__ X, ThChainArgs a, int64_t npix, int HW, int Ch, float eps) {
+__global__ __launch_bounds__(512, 2) void tcn_chain_fwd_kernel(const bf16* __restrict__ X, ThChainArgs a, int64_t npix, int HW, int Ch, float eps, int dyn) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   frag8* wl = reinterpret_cast<frag8*>(smem);                      // [3][THC_IMG]
   frag8* wlh = wl + 3 * THC_IMG;                                   // [2][64]
@@ -274,9 +274,16 @@ __global__ __launch_bounds__(512, 2) void tcn_chain_fwd_kernel(const bf16* __res
     }
     tab[i] = v;
   }
+  // The workgroup's tiles (blockIdx.x * 8 + (i & 7) + (i >> 3) * 8 * gridDim.x, i = 0, 1, ...) are handed to its waves by a counter in LDS:
+  // when both waves of a SIMD are ready the sequencer issues from the older one, so waves 4-7 run a tile ~40 % slower than waves 0-3
+  // while both are busy (measured in tcn_hot_bwd4: profiles/r03_tcn_bwd_stamps.md) and a static split leaves the older waves idle at the
+  // end.  The forward accumulates nothing across tiles, so which wave computes a tile does not change a bit of the result.
+  int* tctr = reinterpret_cast<int*>(tab + 3 * 256 + 16);
+  if (tid == 0) *tctr = 8;
   __syncthreads();
   const int64_t ntile = (npix + 15) >> 4;
   const int64_t tstep = (int64_t)gridDim.x * 8;
+  auto tile_of = [&](int i) -> int64_t { return (int64_t)blockIdx.x * 8 + (i & 7) + (int64_t)(i >> 3) * tstep; };
   auto rows = [&](int64_t tile, bool& valid) -> int64_t {          // element offset of (t = 0, this lane's pixel, its channel quarter)
     int64_t pidx = tile * 16 + px;
     valid = pidx < npix;
@@ -287,13 +294,16 @@ __global__ __launch_bounds__(512, 2) void tcn_chain_fwd_kernel(const bf16* __res
   Tile2 x[TH_T];
   {
     bool v;
-    const int64_t t0 = (int64_t)blockIdx.x * 8 + wave;
+    const int64_t t0 = tile_of(wave);
     const int64_t r0 = rows(t0 < ntile ? t0 : 0, v);
 #pragma unroll
     for (int t = 0; t < TH_T; ++t) x[t] = th_load(X + r0 + (int64_t)t * HW * 64);
   }
-  for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntile; tile += tstep) {
+  int icur = wave;
+  for (int64_t tile = tile_of(wave); tile < ntile;) {
     bool valid, vn;
+    int inext = icur + 8;                                            // (static order: A/B hook frl_tcn_chain_static_tiles)
+    if (dyn && lane == 0) inext = __hip_atomic_fetch_add(tctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (consumed at the end of the tile)
     const int64_t r0 = rows(tile, valid);
     int lw = lane, z0 = 0;
     asm volatile("" : "+v"(lw), "+s"(z0));                        // opaque per tile: neither the weight fragments nor the 3 x 48 per-channel
@@ -324,9 +334,12 @@ __global__ __launch_bounds__(512, 2) void tcn_chain_fwd_kernel(const bf16* __res
         *reinterpret_cast<bf16x4*>(a.h + hrow + (int64_t)t * HW * Ch) = bf16x4{(bf16)ha[0], (bf16)ha[1], (bf16)ha[2], (bf16)ha[3]};
     }
     {                                                               // next tile's rows
-      const int64_t rn = rows(tile + tstep < ntile ? tile + tstep : tile, vn);
+      icur = __builtin_amdgcn_readfirstlane(inext);
+      const int64_t tnext = tile_of(icur);
+      const int64_t rn = rows(tnext < ntile ? tnext : tile, vn);
 #pragma unroll
       for (int t = 0; t < TH_T; ++t) x[t] = th_load(X + rn + (int64_t)t * HW * 64);
+      tile = tnext;
     }
   }
 }
@@ -827,6 +840,9 @@ int frl_tcn_hot_fwd(const void* x, const void* drop_mask, const float* conv_w, c
 // The dense phase chain forward in one launch: x [B][5][HW][64] -> y1, y2, y3 (outputs of the blocks with dilation 1, 2, 4; same shape) and
 // h [B][5][HW][Ch] = head_w y3 + head_b (Ch <= 16, a multiple of 4).  Block parameters as in frl_tcn_hot_fwd, one set per block.
 size_t frl_tcn_chain_fwd_workspace_bytes(void) { return 3 * TH_PACK_BYTES + 4096; }
+// A/B hook: 1 = every wave walks its own fixed tile sequence (the round-3 first version), 0 (default) = tiles handed out by an LDS counter
+static int g_thc_static = 0;
+int frl_tcn_chain_static_tiles(int on) { const int was = g_thc_static; g_thc_static = on ? 1 : 0; return was; }
 int frl_tcn_chain_fwd(const void* x, const float* const* conv_w, const float* const* conv_b, const float* const* gn_w, const float* const* gn_b,
                       const float* const* gate_w, const float* const* gate_b, const float* head_w, const float* head_b, void* y1, void* y2, void* y3,
                       void* h, int64_t npix, int HW, int Ch, float eps, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -851,9 +867,9 @@ int frl_tcn_chain_fwd(const void* x, const float* const* conv_w, const float* co
   a.y[0] = (bf16*)y1; a.y[1] = (bf16*)y2; a.y[2] = (bf16*)y3; a.h = (bf16*)h;
   int64_t g = ((npix + 15) / 16 + 7) / 8;
   if (g > 256) g = 256;
-  const size_t lds = (size_t)(3 * THC_IMG + 2 * 64) * sizeof(frag8) + (3 * 256 + 16) * sizeof(float);
+  const size_t lds = (size_t)(3 * THC_IMG + 2 * 64) * sizeof(frag8) + (3 * 256 + 16) * sizeof(float) + 16;      // (+ the tile counter)
   FRL_HIP(hipFuncSetAttribute((const void*)tcn_chain_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  FRL_LAUNCH(tcn_chain_fwd_kernel, dim3((unsigned)g), dim3(512), lds, stream, (const bf16*)x, a, npix, HW, Ch, eps);
+  FRL_LAUNCH(tcn_chain_fwd_kernel, dim3((unsigned)g), dim3(512), lds, stream, (const bf16*)x, a, npix, HW, Ch, eps, g_thc_static ? 0 : 1);
   return frl_check_launch("tcn_chain_fwd");
 }
 
