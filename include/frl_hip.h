@@ -297,6 +297,9 @@ int frl_tcn_hot_force_generic_tiles(int on);   /* returns the previous setting *
  * workgroup over 32-pixel tiles), 3 = tcn_hot_bwd3_kernel (8 waves in lockstep over 64-pixel tiles).  Same results up to the rounding
  * of dres (bf16); returns the previous setting.  For A/B measurements and the parity tests of both kernels. */
 int frl_tcn_hot_bwd_variant(int v);
+/* Tuning hook of tcn_hot_bwd4: subgroup 0's share (in 32nds, 1..31) of a workgroup's tiles for variant 0 (with dx), 1 (without dx), 2 (head);
+ * returns the previous value (share outside 1..31: query only).  Any value gives the same gradients up to float32 summation order. */
+int frl_tcn_hot_bwd4_share(int variant, int share);
 
 /* ---- optimizer step (frl/training/representation/step.py:1081-1087: clip_grad_norm_(1.0) then AdamW.step()) ---------------
  * Two launches for the whole parameter set.  desc: HOST table of ntensors records {float* p; const float* g; float* m; float* v;

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd4_kernel(const bf16* __rest
                                                               const float* __restrict__ bc, const float* __restrict__ gn_w,
                                                               const float* __restrict__ gn_b, const float* __restrict__ bg, bf16* __restrict__ DX,
                                                               float* __restrict__ slab, int ntile, int HW, float eps,
-                                                              const frag8* __restrict__ Whp, int Chd) {
+                                                              const frag8* __restrict__ Whp, int Chd, int share0_arg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tab = reinterpret_cast<float*>(smem + B4_TAB);
   float* gacc_lds = reinterpret_cast<float*>(smem + B4_GACC);
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd4_kernel(const bf16* __rest
   if (b4_knob[0] == 2 && sg == 1) __builtin_amdgcn_s_setprio(3);
   if (b4_knob[0] == 3 && sg == 0) __builtin_amdgcn_s_setprio(1);
 #else
-  const int share0 = B4_SHARE0;
+  const int share0 = share0_arg;
 #endif
   const int n0 = (n_wg * share0 + 16) >> 5;
   const int i_beg = sg ? n0 : 0, i_end = sg ? n_wg : n0;
@@ -614,6 +614,15 @@ __global__ __launch_bounds__(512, 2) void tcn_hot_bwd4_kernel(const bf16* __rest
 
 bool th_bwd4_supported(int64_t npix, int HW) { return HW > 0 && HW % 64 == 0 && npix % HW == 0 && npix / 32 < ((int64_t)1 << 30); }
 
+// subgroup 0's share of the tiles (32nds) per variant: with dx, without dx, head; test / tuning hook frl_tcn_hot_bwd4_share
+static int g_b4_share[3] = {B4_SHARE0, B4_SHARE0 + 1, B4_SHARE0};   // (tools/diag/bwd4_share_ab.py: 19 / 20 / 19 of 32 are the minima: 223.5, 173.1, 202.4 us per call)
+extern "C" int frl_tcn_hot_bwd4_share(int variant, int share) {
+  if (variant < 0 || variant > 2) return -1;
+  const int was = g_b4_share[variant];
+  if (share >= 1 && share <= 31) g_b4_share[variant] = share;
+  return was;
+}
+
 template <int DIL>
 static void b4_launch(const void* x, const void* dy, const frag8* pk, const float* bc, const float* gw, const float* gb, const float* bg, void* dx,
                       float* slab, unsigned grid, int ntile, int HW, float eps, hipStream_t st) {
@@ -621,12 +630,12 @@ static void b4_launch(const void* x, const void* dy, const frag8* pk, const floa
     auto kern = tcn_hot_bwd4_kernel<DIL, true, false>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B4_LDS);
     FRL_LAUNCH_AS("tcn_hot_bwd4_kernel", kern, dim3(grid), dim3(512), B4_LDS, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx, slab, ntile, HW, eps,
-                  (const frag8*)nullptr, 0);
+                  (const frag8*)nullptr, 0, g_b4_share[0]);
   } else {
     auto kern = tcn_hot_bwd4_kernel<DIL, false, false>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B4_LDS);
     FRL_LAUNCH_AS("tcn_hot_bwd4_nodx_kernel", kern, dim3(grid), dim3(512), B4_LDS, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)nullptr, slab, ntile, HW, eps,
-                  (const frag8*)nullptr, 0);
+                  (const frag8*)nullptr, 0, g_b4_share[1]);
   }
 }
 
@@ -639,7 +648,7 @@ int th_bwd4_launch(int dilation, const void* x, const void* dy, const frag8* pk,
     auto kern = tcn_hot_bwd4_kernel<4, true, true>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B4_LDS + 4096));
     FRL_LAUNCH_AS("tcn_hot_bwd4_head_kernel", kern, dim3(grid), dim3(512), B4_LDS + 4096, st, (const bf16*)x, (const bf16*)dy, pk, bc, gw, gb, bg, (bf16*)dx, slab, ntile, HW,
-                  eps, whp, chd);
+                  eps, whp, chd, g_b4_share[2]);
     return 0;
   }
   if (dilation == 1) b4_launch<1>(x, dy, pk, bc, gw, gb, bg, dx, slab, grid, ntile, HW, eps, st);
