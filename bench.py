@@ -326,7 +326,7 @@ def main():
         # --- dominant kernel -> headline roofline object
         # dominant kernel FAMILY among those with a per-launch work model below (the fused TCN kernels at the measured configuration)
         # (kernel families with a per-launch work model; time = the library-side event pairs around the kernel launches themselves)
-        fam = {"tcn_block_bwd.main": "tcn_hot_bwd4_kernel", "tcn_block_bwd.nodx": "tcn_hot_bwd4_nodx_kernel", "tcn_block_fwd": "tcn_hot_fwd",
+        fam = {"tcn_block_bwd.main": "tcn_hot_bwd4_kernel", "tcn_block_bwd.nodx": "tcn_hot_bwd4_nodx_kernel", "tcn_block_bwd.head": "tcn_hot_bwd4_head_kernel", "tcn_block_fwd": "tcn_hot_fwd",
                "tcn_chain_fwd": "tcn_chain_fwd_kernel", "vq_assign": "vq_assign_kernel", "edge_smooth_fwd": "smooth_fwd_bf16",
                "edge_smooth_bwd": "smooth_bwd_bf16", "smooth_heads_fwd": "smooth_heads_fwd_kernel", "smooth_heads_bwd": "smooth_heads_bwd_kernel",
                "smooth_dx": "smooth_dx"}
@@ -387,7 +387,7 @@ def profiled_kernel_us(substr):
 
 def pmc_traffic(name):
     """HBM bytes per launch from the newest committed rocprofv3 --pmc passes (profiles/*_pmc.json), or None."""
-    key = {"tcn_block_bwd.main": "tcn_hot_bwd4_kernel<", "tcn_block_bwd.nodx": "tcn_hot_bwd4_kernel<", "tcn_block_fwd": "tcn_hot_fwd_kernel",
+    key = {"tcn_block_bwd.main": ", true, false>", "tcn_block_bwd.nodx": ", false, false>", "tcn_block_bwd.head": ", true, true>", "tcn_block_fwd": "tcn_hot_fwd_kernel",
            "tcn_chain_fwd": "tcn_chain_fwd_kernel", "vq_assign": "vq_assign", "edge_smooth_bwd": "smooth_bwd_bf16r4_kernel",
            "smooth_heads_fwd": "smooth_heads_fwd_kernel", "smooth_heads_bwd": "smooth_heads_bwd_kernel", "smooth_dx": "smooth_dx",
            "conv1x1_bwd_weight": "pw_wgrad_kernel"}.get(name)
@@ -425,6 +425,10 @@ def roofline_for(name, ksum, args, model, n, s):
         elif name == "tcn_block_bwd.nodx":                          # the block whose input is the tile itself: no conv^T, no dx
             flops = rows * 2 * 64 * 64 * (2 * taps + 3)
             nbytes = rows * 64 * s * 2
+        elif name == "tcn_block_bwd.head":                          # the last block fed with the head's output gradient dh [rows][zp]
+            zp = model.z_phase_dim
+            flops = rows * (2 * 64 * 64 * (3 * taps + 3) + 2 * 2 * 64 * zp)
+            nbytes = rows * s * (64 * 2 + zp)
         else:
             flops = rows * 2 * 64 * 64 * (3 * taps + 3)             # conv recompute, gate, gate^T, conv^T, two weight-gradient GEMMs
             nbytes = rows * 64 * s * 3                              # x, dy read; dx written
