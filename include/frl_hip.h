@@ -133,6 +133,10 @@ int frl_scalar_fanout(const float* g, const float* coef_host, int n, float* out,
  * that a captured graph reads at replay time */
 int frl_scalar_combine_dev(const float* const* terms_host, const float* coef_host, const float* const* mult_host, int n, float* out,
                            float* ok_out, frl_stream_t stream);
+/* frl_scalar_combine_dev plus a second, un-scheduled combination of the same terms: aux_out[0] = sum_i aux_coef[i] * *terms[i] (a reported
+ * sub-total such as vq_loss = L_codebook + beta L_commit of scripts/train_vqvae.py:236-248) in the same launch. */
+int frl_scalar_combine_aux(const float* const* terms_host, const float* coef_host, const float* const* mult_host, const float* aux_coef_host,
+                           int n, float* out, float* ok_out, float* aux_out, frl_stream_t stream);
 int frl_scalar_fanout_dev(const float* g, const float* coef_host, const float* const* mult_host, int n, float* out, frl_stream_t stream);
 
 /* ---- fused two-layer type encoder (csrc/enc_fused.hip) -----------------------------------------------------------
@@ -240,9 +244,9 @@ int frl_tcn_block_bwd_fused(const void* x, const void* dy, const float* conv_w, 
 /* ---- deferred weight-gradient reductions (csrc/defer.hip) -------------------------------------------------------------------------
  * Every weight-gradient kernel leaves per-workgroup float32 slabs that a small fixed-order reduction turns into the gradient tensors.
  * Between frl_defer_begin() and frl_defer_flush(stream) those reductions (of frl_tcn_hot_bwd, frl_conv3x3_bwd_weight,
- * frl_decoder_mse_bwd, frl_encoder2_bwd, frl_film_fused_bwd, frl_smooth_heads_bwd and frl_conv1x1_bwd_weight; calls that cut their
- * output channels into several slices are not deferred, nor is the codebook gradient, whose epilogue reads tensors of the backward pass)
- * are parked and the flush runs them all in ONE launch: same summation order, bit-identical gradients, ~12 launches fewer per
+ * frl_decoder_mse_bwd, frl_encoder2_bwd, frl_film_fused_bwd, frl_smooth_heads_bwd, frl_conv1x1_bwd_weight and frl_vq_bwd without per-code
+ * sums -- whose epilogue reads `counts`, the codebook and `gscale` when it runs: those three stay alive and unchanged until the flush;
+ * calls that cut their output channels into several slices are not deferred) are parked and the flush runs them all in ONE launch: same summation order, bit-identical gradients, ~12 launches fewer per
  * train step.  The caller owns two promises: the workspaces handed to the deferred calls stay untouched until the flush (hand every
  * call its own), and nothing reads the gradient tensors before it.  frl_defer_destinations lists the gradient pointers of the parked
  * jobs so that the caller can check they still are the tensors its optimizer reads.  Process-wide state (any thread's calls are

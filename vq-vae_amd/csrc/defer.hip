@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void slab_reduce_jobs_kernel(const FrlDeferTab
       case FrlEpiKind<FilmEpi>::id: defer_epi<FilmEpi>(job.payload, i, s); break;
       case FrlEpiKind<ShEpi>::id: defer_epi<ShEpi>(job.payload, i, s); break;
       case FrlEpiKind<WgradEpi>::id: defer_epi<WgradEpi>(job.payload, i, s); break;
+      case FrlEpiKind<CodeEpi>::id: defer_epi<CodeEpi>(job.payload, i, s); break;
       default: break;
     }
   }
@@ -129,6 +130,7 @@ int frl_defer_destinations(void** out, int max) {
       case FrlEpiKind<FilmEpi>::id: { FilmEpi e; memcpy(&e, j.payload, sizeof(e)); put(e.dw1g); put(e.dw1b); put(e.dw2g); put(e.dw2b); put(e.db1g); put(e.db1b); put(e.db2g); put(e.db2b); break; }
       case FrlEpiKind<ShEpi>::id: { ShEpi e; memcpy(&e, j.payload, sizeof(e)); put(e.dwb); put(e.dwa); put(e.dbb); put(e.dba); break; }
       case FrlEpiKind<WgradEpi>::id: { WgradEpi e; memcpy(&e, j.payload, sizeof(e)); put(e.dW); put(e.dB); break; }
+      case FrlEpiKind<CodeEpi>::id: { CodeEpi e; memcpy(&e, j.payload, sizeof(e)); put(e.gE); break; }
       default: break;
     }
   }

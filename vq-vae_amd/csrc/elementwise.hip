@@ -208,12 +208,19 @@ static inline unsigned ew_grid(int64_t n) {
 
 // m[i] (optional): a device scalar that multiplies coef[i] -- a weight that follows a per-step schedule (lambda_vq(step)) without being
 // baked into a captured graph as a kernel argument
-struct ScalarTerms { const float* p[8]; const float* m[8]; float c[8]; };
-__global__ void scalar_combine_kernel(ScalarTerms t, int n, float* __restrict__ out, float* __restrict__ ok_out) {
-  float s = 0.f;
-  for (int i = 0; i < n; ++i) s = fmaf(t.m[i] != nullptr ? t.c[i] * *t.m[i] : t.c[i], *t.p[i], s);
+struct ScalarTerms { const float* p[8]; const float* m[8]; float c[8]; float a[8]; };
+// aux_out (optional): a second, un-scheduled combination aux = sum_i a[i] * term_i of the same terms (a reported sub-total such as
+// vq_loss = L_codebook + beta L_commit, which would otherwise be a launch of its own in the forward and one in the backward)
+__global__ void scalar_combine_kernel(ScalarTerms t, int n, float* __restrict__ out, float* __restrict__ ok_out, float* __restrict__ aux_out) {
+  float s = 0.f, a = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const float v = *t.p[i];
+    s = fmaf(t.m[i] != nullptr ? t.c[i] * *t.m[i] : t.c[i], v, s);
+    a = fmaf(t.a[i], v, a);
+  }
   out[0] = s;
   if (ok_out != nullptr) ok_out[0] = (s * 0.f == 0.f) ? 1.f : 0.f;   // x * 0 == 0 holds exactly for finite x
+  if (aux_out != nullptr) aux_out[0] = a;
 }
 __global__ void scalar_fanout_kernel(const float* __restrict__ g, ScalarTerms t, int n, float* __restrict__ out) {
   if ((int)threadIdx.x < n) {
@@ -225,6 +232,8 @@ __global__ void scalar_fanout_kernel(const float* __restrict__ g, ScalarTerms t,
 extern "C" {
 int frl_scalar_combine_dev(const float* const* terms_host, const float* coef_host, const float* const* mult_host, int n, float* out, float* ok_out,
                            hipStream_t stream);
+int frl_scalar_combine_aux(const float* const* terms_host, const float* coef_host, const float* const* mult_host, const float* aux_coef_host, int n,
+                           float* out, float* ok_out, float* aux_out, hipStream_t stream);
 int frl_scalar_fanout_dev(const float* g, const float* coef_host, const float* const* mult_host, int n, float* out, hipStream_t stream);
 
 size_t frl_mse_workspace_bytes(void) { return (size_t)EW_GRID_MAX * 2 * sizeof(double); }
@@ -340,14 +349,21 @@ int frl_scalar_combine(const float* const* terms_host, const float* coef_host, i
 // pointers, entries or the array itself may be NULL).  A weight that changes every step is then a device word, not a kernel argument.
 int frl_scalar_combine_dev(const float* const* terms_host, const float* coef_host, const float* const* mult_host, int n, float* out, float* ok_out,
                            hipStream_t stream) {
+  return frl_scalar_combine_aux(terms_host, coef_host, mult_host, nullptr, n, out, ok_out, nullptr, stream);
+}
+// The same plus aux_out[0] = sum_i aux_coef[i] * *terms[i] (aux_coef_host / aux_out may be NULL together).
+int frl_scalar_combine_aux(const float* const* terms_host, const float* coef_host, const float* const* mult_host, const float* aux_coef_host, int n,
+                           float* out, float* ok_out, float* aux_out, hipStream_t stream) {
   if (n < 1 || n > 8) return frl_fail(-2, "scalar_combine: 1..8 terms");
+  if ((aux_coef_host == nullptr) != (aux_out == nullptr)) return frl_fail(-2, "scalar_combine: aux coefficients and aux output come as a pair");
   ScalarTerms t;
   for (int i = 0; i < 8; ++i) {
     t.p[i] = i < n ? terms_host[i] : nullptr;
     t.m[i] = (i < n && mult_host != nullptr) ? mult_host[i] : nullptr;
     t.c[i] = i < n ? coef_host[i] : 0.f;
+    t.a[i] = (i < n && aux_coef_host != nullptr) ? aux_coef_host[i] : 0.f;
   }
-  FRL_LAUNCH(scalar_combine_kernel, dim3(1), dim3(1), 0, stream, t, n, out, ok_out);
+  FRL_LAUNCH(scalar_combine_kernel, dim3(1), dim3(1), 0, stream, t, n, out, ok_out, aux_out);
   return frl_check_launch("scalar_combine");
 }
 // Backward of frl_scalar_combine: out[i] = g[0] * coef[i] (* *mult[i]).
@@ -361,6 +377,7 @@ int frl_scalar_fanout_dev(const float* g, const float* coef_host, const float* c
     t.p[i] = nullptr;
     t.m[i] = (i < n && mult_host != nullptr) ? mult_host[i] : nullptr;
     t.c[i] = i < n ? coef_host[i] : 0.f;
+    t.a[i] = 0.f;
   }
   FRL_LAUNCH(scalar_fanout_kernel, dim3(1), dim3(8), 0, stream, g, t, n, out);
   return frl_check_launch("scalar_fanout");

@@ -108,8 +108,8 @@ struct WgradEpi {
 };
 
 // codebook gradient of the vector quantizer (vq.hip): per-code sums S[k] = sum_{idx = k} z  ->  g_E = ce (count_k e_k - S_k); the per-code
-// sums themselves (sums_out) feed the EMA update inside the same call and the epilogue READS tensors of the backward pass (counts, the
-// upstream scale) that autograd releases when the node is done, so this reduction is never deferred
+// sums themselves (sums_out) feed the EMA update inside the same call, so the job is deferrable only without them; the epilogue READS
+// counts, E and the upstream scale when it runs: a caller that defers keeps those three alive and unchanged until the flush
 struct CodeEpi {
   const float* E; const int32_t* counts; const float* gscale; float ce_base; int d, bf; float* gE; float* sums_out;
   __device__ void operator()(int64_t i, float s) const {
@@ -131,3 +131,4 @@ template <> struct FrlEpiKind<EncEpi> { static constexpr int id = 4; };
 template <> struct FrlEpiKind<FilmEpi> { static constexpr int id = 5; };
 template <> struct FrlEpiKind<ShEpi> { static constexpr int id = 6; };
 template <> struct FrlEpiKind<WgradEpi> { static constexpr int id = 7; };
+template <> struct FrlEpiKind<CodeEpi> { static constexpr int id = 8; };

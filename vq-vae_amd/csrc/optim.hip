@@ -29,9 +29,16 @@ struct FrlParamBatch { FrlParamDesc d[OPT_BATCH]; };
 // counters [2] (device, optional): {updates applied, updates skipped}.  With an `ok` flag the whole update is conditional ON THE DEVICE
 // (the reference's isfinite guard, step.py:1057-1074, without a host synchronisation): ok[0] <= 0 -> parameters, moments and the update
 // count stay untouched and counters[1] is incremented.
+// (count_ok / counters: the FIRST squared-norm launch of a step also bumps the update counters -- applied or skipped -- so that the AdamW
+// launches behind it read the new count and no separate one-thread launch is needed)
 __global__ __launch_bounds__(256) void frl_grad_sqnorm_kernel(const FrlParamBatch tab, int tbase, const int2* __restrict__ chunks,
-                                                              int nchunks, double* __restrict__ partial) {
+                                                              int nchunks, double* __restrict__ partial, const float* __restrict__ count_ok,
+                                                              int* __restrict__ counters) {
   __shared__ double red[4];
+  if (counters != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    const bool go = (count_ok == nullptr) || (count_ok[0] > 0.f);
+    counters[go ? 0 : 1] += 1;
+  }
   double s = 0.0;
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
     const int2 ck = chunks[c];
@@ -57,8 +64,8 @@ __global__ __launch_bounds__(256) void frl_adamw_kernel(const FrlParamBatch tab,
   if (lr_dev != nullptr) lr = lr_dev[0];                     // learning rate kept on the device (a captured graph replays with new values)
   const bool go = (ok == nullptr) || (ok[0] > 0.f);
   // update number: device counter + 1 when the caller keeps one (exact under skipped batches), else the host's count
-  const int step = (counters != nullptr) ? counters[0] + 1 : step_host;
-  (void)last_batch;                                          // counters are bumped by frl_opt_count_kernel after all batches ran
+  const int step = (counters != nullptr) ? counters[0] : step_host;   // (already bumped by the step's first frl_grad_sqnorm_kernel launch)
+  (void)last_batch;
   if (!go) return;
   if (threadIdx.x < 64) {
     double s = 0.0;
@@ -120,11 +127,6 @@ __global__ __launch_bounds__(256) void frl_multi_copy_kernel(const FrlCopyBatch 
   }
 }
 
-__global__ void frl_opt_count_kernel(const float* __restrict__ ok, int* __restrict__ counters) {
-  const bool go = (ok == nullptr) || (ok[0] > 0.f);
-  counters[go ? 0 : 1] += 1;
-}
-
 // Splits the chunk table (sorted by tensor, host copy in chunk_tensor) into runs that reference at most `batch` tensors.
 static int opt_batch_end(const int* chunk_tensor, int nchunks, int c0, int t0, int batch) {
   int c = c0;
@@ -179,7 +181,8 @@ int frl_adamw_clip_step(const void* desc_host, int ntensors, const void* chunks,
       if (c1 > c0) {
         const int grid = (c1 - c0) < 512 ? (c1 - c0) : 512;
         if (pass == 0) {
-          FRL_LAUNCH(frl_grad_sqnorm_kernel, dim3(grid), dim3(256), 0, stream, tab, t0, (const int2*)chunks + c0, c1 - c0, partial + poff);
+          FRL_LAUNCH(frl_grad_sqnorm_kernel, dim3(grid), dim3(256), 0, stream, tab, t0, (const int2*)chunks + c0, c1 - c0, partial + poff, ok,
+                     poff == 0 ? counters : (int*)nullptr);
           poff += grid;
         } else {
           FRL_LAUNCH(frl_adamw_kernel, dim3(grid), dim3(256), 0, stream, tab, t0, (const int2*)chunks + c0, c1 - c0, (const double*)partial,
@@ -190,7 +193,6 @@ int frl_adamw_clip_step(const void* desc_host, int ntensors, const void* chunks,
     }
     if (pass == 0) npartial = poff;
   }
-  if (counters != nullptr) FRL_LAUNCH(frl_opt_count_kernel, dim3(1), dim3(1), 0, stream, ok, counters);
   return frl_check_launch("adamw_clip_step");
 }
 

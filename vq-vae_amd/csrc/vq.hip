@@ -1519,7 +1519,7 @@ int frl_vq_bwd(const void* g_out, const void* z, const void* zq, const float* E,
     if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     FRL_LAUNCH_AS("vq_bwd_kernel", kern, dim3(VQ_BWD_WGS), dim3(256), lds, stream, (const float*)g_out, (const float*)z, E, idx, gscale,
                        cz, N, K, d, Kc, rows, (float*)g_z_out, slab);
-    launch_slab_reduce<float, CodeEpi>((const float*)slab, VQ_BWD_WGS, (int64_t)K * d, CodeEpi{E, counts, gscale, ce, d, 0, g_E_out, sums_out}, stream);
+    launch_slab_reduce_deferrable<float, CodeEpi>((const float*)slab, VQ_BWD_WGS, (int64_t)K * d, CodeEpi{E, counts, gscale, ce, d, 0, g_E_out, sums_out}, stream, sums_out == nullptr);
   } else if (dtype == FRL_BF16) {
     const int64_t rows64 = (rows + 63) / 64 * 64;
     if (d <= 32) {
@@ -1532,7 +1532,7 @@ int frl_vq_bwd(const void* g_out, const void* z, const void* zq, const float* E,
       FRL_LAUNCH((vq_bwd_mfma_kernel<2, 8, 8>), dim3(VQ_BWD_WGS), dim3(512), (size_t)64 * 136 * 2 + 256, stream, (const bf16*)g_out, (const bf16*)z, (const bf16*)zq, E, idx,
                  gscale, cz, N, K, d, rows64, (bf16*)g_z_out, slab);
     }
-    launch_slab_reduce<float, CodeEpi>((const float*)slab, VQ_BWD_WGS, (int64_t)K * d, CodeEpi{E, counts, gscale, ce, d, 1, g_E_out, sums_out}, stream);
+    launch_slab_reduce_deferrable<float, CodeEpi>((const float*)slab, VQ_BWD_WGS, (int64_t)K * d, CodeEpi{E, counts, gscale, ce, d, 1, g_E_out, sums_out}, stream, sums_out == nullptr);
   } else return frl_fail(-2, "vq_bwd: bad dtype");
   return frl_check_launch("vq_bwd");
 }

@@ -61,6 +61,7 @@ SIGNATURES = {
     "frl_scalar_combine": (c_int, [P, P, I, P, P, P]),
     "frl_scalar_fanout": (c_int, [P, P, I, P, P]),
     "frl_scalar_combine_dev": (c_int, [P, P, P, I, P, P, P]),
+    "frl_scalar_combine_aux": (c_int, [P, P, P, P, I, P, P, P, P]),
     "frl_scalar_fanout_dev": (c_int, [P, P, P, I, P, P]),
     "frl_encoder2_supported": (c_int, [I, I, I, I, I, I, I]),
     "frl_encoder2_workspace_bytes": (S, [I]),

@@ -99,26 +99,28 @@ class Encoder2Fn(Function):
 
 
 class ScalarCombineFn(Function):
-    """sum_i coef_i * term_i over device scalars in one launch (plus its finite flag); backward: one launch for all term gradients."""
+    """sum_i coef_i * term_i over device scalars in one launch (plus its finite flag and, optionally, a second un-differentiated
+    combination of the same terms); backward: one launch for all term gradients."""
 
     @staticmethod
-    def forward(ctx, coefs, mults, *terms):
-        loss, ok = ops.scalar_combine([t.detach() for t in terms], coefs, mults)
+    def forward(ctx, coefs, mults, aux_coefs, *terms):
+        res = ops.scalar_combine([t.detach() for t in terms], coefs, mults, aux_coefs)
         ctx.coefs = tuple(float(c) for c in coefs)
         ctx.mults = mults                                           # device scalars (no gradient: schedule values), read again in the backward
-        ctx.mark_non_differentiable(ok)
-        return loss, ok
+        ctx.mark_non_differentiable(*res[1:])
+        return res if aux_coefs is not None else res + (None,)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g, g_ok):
+    def backward(ctx, g, g_ok, g_aux):
         gg = ops.scalar_fanout(g.reshape(1).float().contiguous(), ctx.coefs, ctx.mults)
-        return (None, None) + tuple(gg[i] for i in range(len(ctx.coefs)))
+        return (None, None, None) + tuple(gg[i] for i in range(len(ctx.coefs)))
 
 
-def scalar_combine(terms, coefs, mults=None):
-    """-> (sum_i coef_i * mult_i * term_i [0-dim], ok [1] = 1.0 if finite else 0.0 | None); plain torch arithmetic off the GPU path.
-    mults: optional device float scalars (or None entries) that scale a term's weight at run time (a scheduled loss weight)."""
+def scalar_combine(terms, coefs, mults=None, aux_coefs=None):
+    """-> (sum_i coef_i * mult_i * term_i [0-dim], ok [1] = 1.0 if finite else 0.0 | None[, aux = sum_i aux_coef_i * term_i, detached]); plain
+    torch arithmetic off the GPU path.  mults: optional device float scalars (or None entries) that scale a term's weight at run time (a
+    scheduled loss weight); aux_coefs: a second combination of the same terms from the same launch (no gradient flows through it)."""
     fits = all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.numel() == 1 for t in terms) and 1 <= len(terms) <= 8
     if not fits:
         tot = None
@@ -127,8 +129,13 @@ def scalar_combine(terms, coefs, mults=None):
             if mults is not None and mults[i] is not None:
                 v = v * mults[i].reshape(()).to(v.device)
             tot = v if tot is None else tot + v
-        return tot, None
-    return ScalarCombineFn.apply(tuple(coefs), None if mults is None else tuple(mults), *[t.reshape(()) for t in terms])
+        if aux_coefs is None:
+            return tot, None
+        aux = sum(float(c) * t.detach() for t, c in zip(terms, aux_coefs))
+        return tot, None, aux
+    loss, ok, aux = ScalarCombineFn.apply(tuple(coefs), None if mults is None else tuple(mults), None if aux_coefs is None else tuple(aux_coefs),
+                                          *[t.reshape(()) for t in terms])
+    return (loss, ok) if aux_coefs is None else (loss, ok, aux)
 
 
 class SobelFn(Function):

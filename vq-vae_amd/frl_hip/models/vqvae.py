@@ -57,8 +57,10 @@ class VectorQuantizer(nn.Module):
             self._prepared = (key, ops.vq_prepare(cb.detach(), n_rows, dtype, out=buf))
         return self._prepared[1]
 
-    def forward(self, z_rows: torch.Tensor):
-        """z_rows [N, d] -> (z_q [N,d] with straight-through gradient, vq_loss, perplexity, idx int32 [N])."""
+    def forward(self, z_rows: torch.Tensor, raw_terms: bool = False):
+        """z_rows [N, d] -> (z_q [N,d] with straight-through gradient, vq_loss, perplexity, idx int32 [N]).  raw_terms (gradient quantizer
+        only): vq_loss is returned as its parts ((L_codebook, 1.0), (L_commit, beta)) for a caller that folds them into its own weighted
+        sum of loss terms (VQVAE.forward_tiles: one launch for the total AND the reported vq_loss instead of two)."""
         zq, l_cb, l_cm, perp, idx, counts, stats = Fh.VQFn.apply(z_rows, self.codebook, self.prepared(z_rows.dtype, z_rows.shape[0]))
         self.last_counts = counts
         self.last_stats = stats          # f32 [4]: sum ||z - z_q||^2, perplexity, rows whose arg-min was re-evaluated exactly, mean squared error
@@ -71,6 +73,8 @@ class VectorQuantizer(nn.Module):
                 self._pending_ema = (sums, counts)
                 if not self.defer_ema:
                     self.apply_ema()
+        elif raw_terms:
+            vq_loss = ((l_cb, 1.0), (l_cm, float(self.beta)))
         else:
             vq_loss = Fh.scalar_combine([l_cb, l_cm], [1.0, self.beta])[0]       # one launch (and one in the backward)
         return zq, vq_loss, perp, idx
@@ -199,11 +203,13 @@ class VQVAE(RepresentationModel):
         return out
 
     def forward_tiles(self, tile: torch.Tensor, mask: Optional[torch.Tensor] = None,
-                      return_recon: bool = False) -> Dict[str, torch.Tensor]:
+                      return_recon: bool = False, differentiable_vq_loss: bool = False) -> Dict[str, torch.Tensor]:
         """tile [B,T,H,W,F] (any float dtype, GPU) -> dict(loss, l_type, l_phase, vq_loss, perplexity, idx, ...).
         `mask` (1 = valid) is per pixel [B,H,W] or per observation [B,T,H,W] (as `TilePrefetcher` delivers it); with the latter the
         type-path loss counts a pixel only if all its time steps are valid (its input is their mean).
-        `xhat_type` / `xhat_phase` are present when return_recon=True or when the modular decoder path is taken."""
+        `xhat_type` / `xhat_phase` are present when return_recon=True or when the modular decoder path is taken.
+        out["vq_loss"] is a reported value (no gradient flows through it; out["loss"] carries the quantizer's gradients) unless
+        differentiable_vq_loss=True, which the legacy contract asks for: its caller builds the total loss itself."""
         self._require_gpu(tile)
         tile = self._rows(tile)
         b, t, hh, ww, f = tile.shape
@@ -222,13 +228,25 @@ class VQVAE(RepresentationModel):
             with torch.cuda.stream(side):
                 ph = self._phase_branch(tile, zt, mask, return_recon)
         d = z_type.shape[-1]
-        zq, vq_loss, perp, idx = self.quant(z_type.reshape(-1, d))
+        # gradient quantizer on the GPU: its two loss parts join the total below directly (one launch yields the total, the flag and vq_loss)
+        split_vq = self.quant.quantizer != "ema" and z_type.is_cuda and not differentiable_vq_loss
+        zq, vq_loss, perp, idx = self.quant(z_type.reshape(-1, d), raw_terms=split_vq)
+        vq_parts = vq_loss if split_vq else None
         tmask = mask.amin(dim=1) if (mask is not None and mask.dim() == 4) else mask
         l_type, xhat_type = self._decode_loss(self.decoder_type, zq.reshape(b, hh, ww, d), x_type, tmask, return_recon)
-        out = dict(z_type=z_type, gate=gate, idx=idx, vq_loss=vq_loss, perplexity=perp, l_type=l_type, vq_stats=self.quant.last_stats)
+        out = dict(z_type=z_type, gate=gate, idx=idx, vq_loss=None if split_vq else vq_loss, perplexity=perp, l_type=l_type,
+                   vq_stats=self.quant.last_stats)
         if xhat_type is not None:
             out["xhat_type"] = xhat_type
-        terms = [(l_type, self.lambda_recon), self._vq_term(vq_loss)]
+        if split_vq:
+            terms = [(l_type, self.lambda_recon)]
+            for part, w in vq_parts:                                    # lambda_vq * (L_codebook + beta * L_commit), term by term
+                t = self._vq_term(part)
+                terms.append((t[0], t[1] * w) + tuple(t[2:]))
+            aux = [0.0] + [w for _, w in vq_parts]
+        else:
+            terms = [(l_type, self.lambda_recon), self._vq_term(vq_loss)]
+            aux = None
         if self.phase:
             if side is not None:
                 main.wait_stream(side)
@@ -240,7 +258,11 @@ class VQVAE(RepresentationModel):
             terms += ph.pop("loss_terms")
             out.update(ph)
         # weighted sum of the loss terms and its isfinite flag in ONE launch (the trainer's device-side guard reads out["loss_ok"])
-        loss, ok = Fh.scalar_combine([t[0] for t in terms], [float(t[1]) for t in terms], [t[2] if len(t) > 2 else None for t in terms])
+        res = Fh.scalar_combine([t[0] for t in terms], [float(t[1]) for t in terms], [t[2] if len(t) > 2 else None for t in terms],
+                                aux_coefs=None if aux is None else aux + [0.0] * (len(terms) - len(aux)))
+        loss, ok = res[0], res[1]
+        if aux is not None:
+            out["vq_loss"] = res[2]                                     # L_codebook + beta L_commit (reported value: no gradient flows through it)
         out["loss"] = loss
         if ok is not None:
             out["loss_ok"] = ok
@@ -323,6 +345,6 @@ class VQVAE(RepresentationModel):
 
         A tensor argument keeps the RepresentationModel.forward semantics ([B,C,H,W] -> z_type)."""
         if isinstance(batch, dict):
-            out = self.forward_tiles(batch["tile"], batch.get("mask"), return_recon=True)
+            out = self.forward_tiles(batch["tile"], batch.get("mask"), return_recon=True, differentiable_vq_loss=True)
             return out["xhat_type"], {}, out.get("xhat_phase"), out["vq_loss"], out["perplexity"]
         return super().forward(batch, return_gate)

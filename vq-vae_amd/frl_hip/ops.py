@@ -366,7 +366,10 @@ def vq_bwd(g_out: Optional[torch.Tensor], z: torch.Tensor, codebook: torch.Tenso
     gz = torch.empty_like(z) if want_gz else None
     ge = torch.empty(k, d, dtype=torch.float32, device=z.device) if want_ge else None
     sums = torch.empty(k, d, dtype=torch.float32, device=z.device) if want_sums else None
-    check(lib.frl_vq_bwd(_p(g_out), _p(z), _p(zq), _p(_f32(codebook, "codebook")), _p(idx), _p(counts), _p(gscale), float(beta),
+    cb32 = _f32(codebook, "codebook")
+    if _DEFER["on"]:                                            # the parked codebook-gradient reduction reads these when the flush runs
+        _DEFER["keep"] += [t for t in (counts, gscale, cb32) if t is not None]
+    check(lib.frl_vq_bwd(_p(g_out), _p(z), _p(zq), _p(cb32), _p(idx), _p(counts), _p(gscale), float(beta),
                          n, k, d, _p(gz), _p(ge), _p(sums), _dt(z), _p(ws), ws.numel(), _stream()), "frl_vq_bwd")
     return gz, ge, sums
 
@@ -392,9 +395,10 @@ def _mult_ptrs(mults, n):
     return (ctypes.c_void_p * n)(*[0 if m is None else m.data_ptr() for m in mults])
 
 
-def scalar_combine(terms, coefs, mults=None):
+def scalar_combine(terms, coefs, mults=None, aux_coefs=None):
     """[device float scalars], [host floats](, [device float scalars | None]) -> (value [] f32 = sum coef_i * mult_i * term_i, ok [1] f32 = 1.0 if
-    the value is finite else 0.0).  A multiplier is read on the device at run time (a scheduled loss weight inside a captured graph)."""
+    the value is finite else 0.0[, aux [] f32 = sum aux_coef_i * term_i]).  A multiplier is read on the device at run time (a scheduled loss
+    weight inside a captured graph); aux_coefs adds a second combination of the same terms to the launch (a reported sub-total)."""
     n = len(terms)
     dev = terms[0].device
     for t in terms:
@@ -404,8 +408,13 @@ def scalar_combine(terms, coefs, mults=None):
     cf = (ctypes.c_float * n)(*[float(c) for c in coefs])
     out = torch.empty((), dtype=torch.float32, device=dev)
     ok = torch.empty(1, dtype=torch.float32, device=dev)
-    check(_lib.load().frl_scalar_combine_dev(ptrs, cf, _mult_ptrs(mults, n), n, _p(out), _p(ok), _stream()), "frl_scalar_combine")
-    return out, ok
+    if aux_coefs is None:
+        check(_lib.load().frl_scalar_combine_dev(ptrs, cf, _mult_ptrs(mults, n), n, _p(out), _p(ok), _stream()), "frl_scalar_combine")
+        return out, ok
+    ac = (ctypes.c_float * n)(*[float(c) for c in aux_coefs])
+    aux = torch.empty((), dtype=torch.float32, device=dev)
+    check(_lib.load().frl_scalar_combine_aux(ptrs, cf, _mult_ptrs(mults, n), ac, n, _p(out), _p(ok), _p(aux), _stream()), "frl_scalar_combine_aux")
+    return out, ok, aux
 
 
 def scalar_fanout(g, coefs, mults=None):
