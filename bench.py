@@ -225,7 +225,10 @@ def main():
         torch.cuda.synchronize()
 
     timing = (not args.no_kernel_timing) and rank == 0
-    graphed = args.graph != "off" and trainer.graph_supported()
+    # auto: the captured graph on one GPU; N > 1 runs the eager data-parallel step (GPU-bound as well: ~1.5 ms of host time against a 2.5 ms
+    # step) -- the capture of the RCCL all-reduces is verified bit for bit at one rank only (RCCL refuses two ranks on the single GPU of the
+    # development box), so it stays opt-in (--graph on) until it has run on a multi-GPU node
+    graphed = args.graph != "off" and trainer.graph_supported() and (world == 1 or args.graph == "on")
     if args.graph == "on" and not graphed:
         raise SystemExit("bench.py: --graph on, but this trainer configuration cannot be captured (data-parallel reducer or a per-step lambda_vq)")
     dt, t_host, last = timed_steps(trainer, stream, args.steps, args.warmup, barrier, graphed)
@@ -271,6 +274,7 @@ def main():
                                f"K={args.codebook}, d={args.emb_dim}, dropout 0.0",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}", "finite_check": not args.no_finite_check,
                    "launch": "hipGraph replay of the whole step (one graph per tile-pool buffer)" if graphed else "eager (one launch per kernel)",
+                   "deferred_reductions": bool(trainer.defer_reductions and not (trainer.reducer is not None and trainer.reducer.active)),
                    "loss": round(float(last["loss"].detach()), 5), "perplexity": round(float(last["perplexity"]), 2),
                    "codebook_init": "encoder outputs of the first batch (VQVAE.init_codebook_from_tiles)" if args.codebook_init == "data"
                    else "randn(K, d), seed 7",
