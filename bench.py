@@ -445,9 +445,13 @@ def roofline_for(name, ksum, args, model, n, s):
         first, second = (hbm, mfma) if hf >= mf else (mfma, hbm)
         base.update(first)
         base["other_ceiling"] = second
+        if name == "tcn_chain_fwd":
+            why = ("issue-bound: three blocks + head per 16-pixel wave tile (~450 MFMAs and the GroupNorm / sigmoid chains of 240 elements per lane), "
+                   "two waves per SIMD, 42 % of the wave time in waits (SQ counters, profiles/r03_mfma_util.json)")
+        else:
+            why = ("issue-bound: ~1770 vector-ALU instructions and 226 MFMAs per wave and 32-pixel tile, two waves per SIMD (one of each subgroup)")
         base["note"] = ("HIP-event pair inside the library around the kernel launch itself (weight pack and slab reduction of the C-ABI call "
-                        "excluded); issue-bound: ~1770 vector-ALU instructions and 226 MFMAs per wave and 32-pixel tile, two waves per SIMD "
-                        "(one of each subgroup): DESIGN.md section 4")
+                        "excluded); " + why + ": DESIGN.md section 4")
         return base
     if name == "vq_assign":
         b = n * (2 * d * s + 4) + args.codebook * d * 4
