@@ -166,7 +166,9 @@ __global__ __launch_bounds__(256) void mean_time_kernel(const T* __restrict__ ti
   const int64_t nv = HWC / V, total = B * nv;
   const float inv = 1.f / (float)Tn;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t j = i % nv, b = i / nv;
+    int64_t j, b;
+    if (total < ((int64_t)1 << 31)) { const unsigned u = (unsigned)i, q = u / (unsigned)nv; b = q; j = u - q * (unsigned)nv; }   // (one 32-bit division, not two 64-bit ones)
+    else { j = i % nv; b = i / nv; }
     float s[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) s[e] = 0.f;

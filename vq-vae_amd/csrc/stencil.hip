@@ -29,15 +29,38 @@ __device__ __forceinline__ bool st_load(const T* __restrict__ X, int b, int y, i
   return true;
 }
 
+// (pixel, channel vector) of flat element i: three 32-bit divisions where the tensor has fewer than 2^31 vectors (always, in practice) instead
+// of five 64-bit ones -- the index arithmetic was most of the instruction stream of these streaming kernels
+struct StIdx { int b, y, x, c0; int64_t p; };
+__device__ __forceinline__ StIdx st_index(int64_t i, int vpr, int V, int H, int W, bool small) {
+  StIdx r;
+  if (small) {
+    const unsigned u = (unsigned)i, p = u / (unsigned)vpr, row = p / (unsigned)W, b = row / (unsigned)H;
+    r.c0 = (int)(u - p * (unsigned)vpr) * V;
+    r.x = (int)(p - row * (unsigned)W);
+    r.y = (int)(row - b * (unsigned)H);
+    r.b = (int)b;
+    r.p = (int64_t)p;
+  } else {
+    r.c0 = (int)(i % vpr) * V;
+    r.p = i / vpr;
+    r.x = (int)(r.p % W);
+    r.y = (int)((r.p / W) % H);
+    r.b = (int)(r.p / ((int64_t)W * H));
+  }
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------------ Sobel
 template <typename T, int V>
 __global__ __launch_bounds__(256) void sobel_fwd_kernel(const T* __restrict__ X, T* __restrict__ G, int B, int H, int W, int C) {
   const int vpr = C / V;
   const int64_t total = (int64_t)B * H * W * vpr;
+  const bool small = total < ((int64_t)1 << 31);
   for (int64_t i = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c0 = (int)(i % vpr) * V;
-    const int64_t p = i / vpr;
-    const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+    const StIdx ix = st_index(i, vpr, V, H, W, small);
+    const int c0 = ix.c0, x = ix.x, y = ix.y, b = ix.b;
+    const int64_t p = ix.p;
     float gx[V], gy[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) { gx[e] = 0.f; gy[e] = 0.f; }
@@ -63,10 +86,11 @@ __global__ __launch_bounds__(256) void sobel_bwd_kernel(const T* __restrict__ DG
                                                         int C) {
   const int vpr = C / V;
   const int64_t total = (int64_t)B * H * W * vpr;
+  const bool small = total < ((int64_t)1 << 31);
   for (int64_t i = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c0 = (int)(i % vpr) * V;
-    const int64_t p = i / vpr;
-    const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+    const StIdx ix = st_index(i, vpr, V, H, W, small);
+    const int c0 = ix.c0, x = ix.x, y = ix.y, b = ix.b;
+    const int64_t p = ix.p;
     float o[V];
     if (DXADD != nullptr) {                                      // gradient of x through its other consumer, accumulated here
       Vec<T>::load(DXADD + p * C + c0, o);
