@@ -379,6 +379,7 @@ int frl_decoder_mse_fwd(const void* z, const float* w1, const float* b1, const f
 int frl_decoder_mse_bwd(const void* z, const float* w1, const float* b1, const float* w2, const float* b2, const void* target,
                         const uint8_t* mask, const float* gscale, const float* stats, void* dz, float* dw1, float* db1,
                         float* dw2, float* db2, int64_t P, int Cz, void* ws, size_t ws_bytes, frl_stream_t stream);
+int frl_decoder_mse_bwd_subgroups(int on);   /* A/B hook: 1 (default) = two independent 4-wave subgroups per workgroup, 0 = lockstep workgroups; returns the previous setting */
 
 /* ---- vector quantizer ------------------------------------------------------------------------------------------
  * Not in the reference tree; constants frl/config/frl_model_v0.yaml:29-35,

@@ -712,9 +712,11 @@ def test_fused_film_matches_float64(B, T, HW):
     assert not ops.film_fused_supported(ztd.float(), hd.float(), 32) and not ops.film_fused_supported(ztd, hd, 16)
 
 
-@pytest.mark.parametrize("P,cz,use_mask", [(4096, 64, False), (5000, 12, True), (333, 12, False), (1000, 32, True), (130, 64, True)])
+@pytest.mark.parametrize("P,cz,use_mask", [(4096, 64, False), (5000, 12, True), (333, 12, False), (1000, 32, True), (130, 64, True), (70001, 12, True)])
 def test_fused_decoder_mse(P, cz, use_mask):
-    """Fused decoder + L2 loss (bf16) vs float64 autograd of the same chain, and vs the modular kernels."""
+    """Fused decoder + L2 loss (bf16) vs float64 autograd of the same chain, and vs the modular kernels.  Latents of <= 32 channels run the
+    backward as two independent 4-wave subgroups per workgroup (70001 rows: more rounds than subgroups, an uneven split and a ragged last
+    round); the lockstep kernel must give the same gradients up to float32 summation order."""
     from frl_hip import functional as Fh
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(P + cz)
@@ -742,6 +744,22 @@ def test_fused_decoder_mse(P, cz, use_mask):
     assert rel_err(zd.grad.float(), z.grad) <= 3e-2
     for got, ref in zip(params, (w1q, b1d, w2q, b2d)):
         assert rel_err(got.grad, ref.grad) <= 3e-2
+    if cz <= 32:
+        from frl_hip import _lib
+        lib = _lib.load()
+        first = [zd.grad.clone()] + [p_.grad.clone() for p_ in params]
+        zd.grad = None
+        for p_ in params:
+            p_.grad = None
+        was = lib.frl_decoder_mse_bwd_subgroups(0)
+        try:
+            l2, _ = Fh.decoder_mse(zd, params[0], params[1], params[2], params[3], tgt.to(dtype).to(DEV), mask.to(DEV) if use_mask else None, True)
+            (0.8 * l2).backward()
+        finally:
+            lib.frl_decoder_mse_bwd_subgroups(was)
+        assert torch.equal(first[0], zd.grad)                          # dz does not depend on who computed the row
+        for a, p_ in zip(first[1:], params):
+            assert rel_err(a, p_.grad.cpu()) <= 1e-4
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 8e-3)])

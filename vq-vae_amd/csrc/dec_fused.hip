@@ -149,30 +149,56 @@ __global__ __launch_bounds__(256) void dec_mse_finalize_kernel(const double* __r
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// NW waves per workgroup, workgroup tile = 16*NW rows.  slab (floats): dW2 [64][128] | dW1 [128][CZP] | db2 [64] | db1 [128]
-template <int NFZ, int NW>
-__global__ __launch_bounds__(64 * NW) void dec_mse_bwd_kernel(const TT* __restrict__ Z, const frag8* __restrict__ Wpk, const float* __restrict__ b1,
+// Barrier of one 4-wave subgroup through a counter in LDS (the scheme of tcn_hot_bwd4.hip): every wave adds 1 and waits until the counter has
+// reached 4 x the number of barriers it has passed; all waves of the workgroup are resident and a subgroup's waves run the same rounds.
+__device__ __forceinline__ void df_sg_sync(unsigned* bar, unsigned& gen, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  gen += 4u;
+  if (lane == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (;;) {
+    const unsigned seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if ((int)(seen - gen) >= 0) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
+#define DF_SG_SHARE0 19      // subgroup 0's share of a workgroup's rounds in 32nds (the older waves of a SIMD run faster: tcn_hot_bwd4.hip)
+
+// NW waves per workgroup (SG = false) or per SUBGROUP (SG = true: the workgroup is two independent 4-wave subgroups, one wave of each per
+// SIMD, each with its own 64-row tiles, rounds, barriers and slab -- the two waves of a SIMD then sit in different phases of the round
+// instead of both waiting at the same barrier); tile = 16*NW rows.  slab (floats): dW2 [64][128] | dW1 [128][CZP] | db2 [64] | db1 [128]
+template <int NFZ, int NW, bool SG = false>
+__global__ __launch_bounds__(SG ? 512 : 64 * NW) void dec_mse_bwd_kernel(const TT* __restrict__ Z, const frag8* __restrict__ Wpk, const float* __restrict__ b1,
                                                                const float* __restrict__ b2, const TT* __restrict__ TGT,
                                                                const uint8_t* __restrict__ mask, const float* __restrict__ gscale,
                                                                const float* __restrict__ stats, TT* __restrict__ DZ, int64_t P, int Cz,
                                                                float* __restrict__ slab) {
-  constexpr int CZP = 32 * NFZ, CB = CZP / 16, R = 16 * NW, NTH = 64 * NW;
+  constexpr int CZP = 32 * NFZ, CB = CZP / 16, R = 16 * NW, NTH = SG ? 512 : 64 * NW;
   constexpr int PX = DF_F + 8, PH = DF_H + 8, PZ = CZP + 8;            // LDS tile pitches (16-byte skew)
+  static_assert(!SG || NW == 4, "subgroups are four waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   frag8* w1 = reinterpret_cast<frag8*>(smem);                 // [8][NFZ][64]     z -> hidden
   frag8* w2 = w1 + 8 * NFZ * 64;                              // [4][4][64]       hidden -> xhat
   frag8* w2t = w2 + 16 * 64;                                  // [8][2][64]       dxhat -> dhidden
   frag8* w1t = w2t + 16 * 64;                                 // [CB][4][64]      dhidden -> dz
   float* tb = reinterpret_cast<float*>(w1t + CB * 4 * 64);    // b1[128] | b2[64]
-  TT* t_dx = reinterpret_cast<TT*>(tb + 192);                 // [R][PX]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int sg = SG ? (tid >> 8) : 0;                          // subgroup: waves 0-3 / 4-7
+  const int wave = SG ? ((tid >> 6) & 3) : (tid >> 6);         // wave inside the workgroup / subgroup
+  constexpr int TILE_ELEMS = R * (PX + 2 * PH + PZ);
+  unsigned* bars = reinterpret_cast<unsigned*>(tb + 192);     // (SG) two arrival counters, 64 bytes apart
+  TT* t_dx = reinterpret_cast<TT*>(tb + 192 + (SG ? 32 : 0)) + sg * TILE_ELEMS;   // [R][PX]
   TT* t_h = t_dx + R * PX;                                    // [R][PH]
   TT* t_dh = t_h + R * PH;                                    // [R][PH]
   TT* t_z = t_dh + R * PH;                                    // [R][PZ]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, kc = lane >> 4, r16 = px;
   const int prow = wave * 16 + px;
   copy_frags_lds<TT>(w1, Wpk, (8 * NFZ + 16 + 16 + CB * 4) * 64, tid, NTH);
   for (int i = tid; i < 192; i += NTH) tb[i] = i < 128 ? b1[i] : b2[i - 128];
+  if (SG && tid < 2) bars[16 * tid] = 0u;
+  unsigned* bar = bars + 16 * sg;
+  unsigned bgen = 0;
+  (void)bar; (void)bgen;
   __syncthreads();
   const float* b1q = tb + 32 * kc;
   const float* b2q = tb + 128 + 16 * kc;
@@ -199,6 +225,16 @@ __global__ __launch_bounds__(64 * NW) void dec_mse_bwd_kernel(const TT* __restri
   const bf16x8 ones = (r16 == 0) ? bf16x8{one, one, one, one, one, one, one, one} : bf16x8{zero, zero, zero, zero, zero, zero, zero, zero};
 
   const int64_t nwt = (P + R - 1) / R;
+  // rounds of this workgroup (SG: of this subgroup): first, step, end
+  int64_t w_first = blockIdx.x, w_end = nwt;
+  const int64_t w_step = gridDim.x;
+  if (SG) {                                                    // the workgroup's rounds blockIdx.x + i gridDim.x, split 19 : 13 between the subgroups
+    const int64_t n_wg = (int64_t)blockIdx.x < nwt ? (nwt - 1 - blockIdx.x) / w_step + 1 : 0;
+    const int64_t n0 = (n_wg * DF_SG_SHARE0 + 16) >> 5;
+    w_first = blockIdx.x + (sg ? n0 : 0) * w_step;
+    w_end = blockIdx.x + (sg ? n_wg : n0) * w_step;
+    if (w_end > nwt) w_end = nwt;
+  }
   // The rows of the next THREE rounds are in flight while a round computes: the workgroup is alone on its CU (LDS) and a round's rows
   // are only ~19 KB, so one round of look-ahead left the kernel bound by memory latency (19 KB per ~3 us per CU = 1.3 TB/s over the chip).
   LQTile<TT, NFZ> zt, z1, z2, zn;
@@ -210,16 +246,16 @@ __global__ __launch_bounds__(64 * NW) void dec_mse_bwd_kernel(const TT* __restri
     lq_load<TT, NFZ>(zz, Z, rc, Cz, kc, fastz);
     lq_load<TT, 2>(tg, TGT, rc, DF_F, kc, true);
   };
-  fetch(zt, tt, (int64_t)blockIdx.x);
-  fetch(z1, t1, (int64_t)blockIdx.x + gridDim.x);
-  fetch(z2, t2, (int64_t)blockIdx.x + 2 * (int64_t)gridDim.x);
-  for (int64_t wt = blockIdx.x; wt < nwt; wt += gridDim.x) {
+  fetch(zt, tt, w_first);
+  fetch(z1, t1, w_first + w_step);
+  fetch(z2, t2, w_first + 2 * w_step);
+  for (int64_t wt = w_first; wt < w_end; wt += w_step) {
     int64_t row = wt * R + prow;
     const bool inb = row < P;
     bool valid = inb;
     if (!inb) row = P - 1;
     if (valid && mask != nullptr) valid = mask[row] != 0;
-    fetch(zn, tn, wt + 3 * (int64_t)gridDim.x);
+    fetch(zn, tn, wt + 3 * w_step);
     float h[32], xh[16];
     LQTile<TT, 4> ht;
     dec_chain<NFZ>(h, xh, zt, w1, w2, b1q, b2q, ht, lane);
@@ -274,7 +310,7 @@ __global__ __launch_bounds__(64 * NW) void dec_mse_bwd_kernel(const TT* __restri
     tile_put<4>(t_h, PH, prow, kc, ht);
     tile_put<4>(t_dh, PH, prow, kc, dht);
     tile_put<NFZ>(t_z, PZ, prow, kc, zt);
-    __syncthreads();
+    if constexpr (SG) df_sg_sync(bar, bgen, lane); else __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < R / 32; ++ks) {
       const int pix0 = ks * 32 + 8 * kc;
@@ -291,11 +327,11 @@ __global__ __launch_bounds__(64 * NW) void dec_mse_bwd_kernel(const TT* __restri
         ab1[r] = mfma16(ah, ones, ab1[r]);
       }
     }
-    __syncthreads();
+    if constexpr (SG) df_sg_sync(bar, bgen, lane); else __syncthreads();
     zt = z1; z1 = z2; z2 = zn;
     tt = t1; t1 = t2; t2 = tn;
   }
-  float* my = slab + (int64_t)blockIdx.x * (DF_F * DF_H + DF_H * CZP + DF_F + DF_H);
+  float* my = slab + (int64_t)(SG ? 2 * blockIdx.x + sg : blockIdx.x) * (DF_F * DF_H + DF_H * CZP + DF_F + DF_H);   // (SG: a slab per subgroup)
 #pragma unroll
   for (int i = 0; i < W2CB; ++i)
 #pragma unroll
@@ -379,7 +415,33 @@ static int launch_dec_bwd(const void* z, const float* w1, const float* b1, const
   return frl_check_launch("decoder_mse_bwd");
 }
 
+// two independent 4-wave subgroups per workgroup (64-row tiles each), a slab per subgroup
+template <int NFZ>
+static int launch_dec_bwd_sg(const void* z, const float* w1, const float* b1, const float* w2, const float* b2, const void* tgt,
+                             const uint8_t* mask, const float* gscale, const float* stats, void* dz, float* dw1, float* db1, float* dw2,
+                             float* db2, int64_t P, int Cz, char* ws, hipStream_t st) {
+  constexpr int CZP = 32 * NFZ, CB = CZP / 16, R = 64;
+  int64_t g = (P + 2 * R - 1) / (2 * R);
+  if (g > 256) g = 256;
+  if (g < 1) g = 1;
+  const unsigned grid = (unsigned)g, nslab = 2 * grid;
+  const size_t slab_n = (size_t)DF_F * DF_H + DF_H * CZP + DF_F + DF_H;
+  const frag8* pk = dec_packed<NFZ>(w1, w2, Cz, 1, reinterpret_cast<frag8*>(ws + ((nslab * slab_n * sizeof(float) + 255) / 256) * 256), st);
+  const size_t lds = (size_t)(8 * NFZ + 16 + 16 + CB * 4) * 64 * sizeof(frag8) + (192 + 32) * sizeof(float) +
+                     (size_t)2 * R * ((DF_F + 8) + 2 * (DF_H + 8) + (CZP + 8)) * sizeof(TT);
+  auto kern = dec_mse_bwd_kernel<NFZ, 4, true>;
+  FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  FRL_LAUNCH_AS("dec_mse_bwd_sg_kernel", kern, dim3(grid), dim3(512), lds, st, (const TT*)z, (const frag8*)pk, b1, b2, (const TT*)tgt, mask, gscale, stats, (TT*)dz, P,
+                Cz, (float*)ws);
+  launch_slab_reduce_deferrable<float, DecEpi>((const float*)ws, (int)nslab, (int64_t)slab_n, DecEpi{dw2, dw1, db2, db1, Cz, CZP, DF_F, DF_H}, st);
+  return frl_check_launch("decoder_mse_bwd");
+}
+
+static int g_dec_subgroups = 1;     // A/B hook (frl_decoder_mse_bwd_subgroups): 0 = the lockstep 8-wave / 4-wave workgroups of round 2
+
 extern "C" {
+
+int frl_decoder_mse_bwd_subgroups(int on) { const int was = g_dec_subgroups; g_dec_subgroups = on ? 1 : 0; return was; }
 
 int frl_decoder_mse_fused_supported(int Cz, int hidden, int F, int dtype) {
   return (dtype == FRL_BF16 && hidden == DF_H && F == DF_F && Cz >= 1 && Cz <= 64) ? 1 : 0;
@@ -388,7 +450,7 @@ int frl_decoder_mse_fused_supported(int Cz, int hidden, int F, int dtype) {
 size_t frl_decoder_mse_workspace_bytes(int64_t P, int Cz) {
   const size_t czp = Cz <= 32 ? 32 : 64;
   const size_t slab_n = (size_t)DF_F * DF_H + DF_H * czp + DF_F + DF_H;
-  const size_t bwd = 256 * slab_n * sizeof(float) + 256 + (size_t)(8 * 2 + 32 + 16) * 64 * 16;
+  const size_t bwd = 512 * slab_n * sizeof(float) + 256 + (size_t)(8 * 2 + 32 + 16) * 64 * 16;     // (a slab per subgroup: two per workgroup)
   const size_t fwd = (size_t)DF_GRID_MAX * 2 * sizeof(double) + 256 + (size_t)(8 * 2 + 16) * 64 * 16;
   (void)P;
   return bwd > fwd ? bwd : fwd;
@@ -428,6 +490,9 @@ int frl_decoder_mse_bwd(const void* z, const float* w1, const float* b1, const f
   if (P <= 0) return frl_fail(-2, "decoder_mse_bwd: empty input");
   if (Cz < 1 || Cz > 64) return frl_fail(-2, "decoder_mse_bwd: latent width must be 1..64");
   if (ws_bytes < frl_decoder_mse_workspace_bytes(P, Cz)) return frl_fail(-4, "decoder_mse_bwd: workspace too small");
+  // (latents of more than 32 channels: the two subgroups' tiles do not fit the LDS beside the four weight images: 172 KB)
+  if (g_dec_subgroups && P >= 128 && Cz <= 32)
+    return launch_dec_bwd_sg<1>(z, w1, b1, w2, b2, target, mask, gscale, stats, dz, dw1, db1, dw2, db2, P, Cz, (char*)ws, stream);
   if (Cz <= 32) return launch_dec_bwd<1, 8>(z, w1, b1, w2, b2, target, mask, gscale, stats, dz, dw1, db1, dw2, db2, P, Cz, (char*)ws, stream);
   return launch_dec_bwd<2, 4>(z, w1, b1, w2, b2, target, mask, gscale, stats, dz, dw1, db1, dw2, db2, P, Cz, (char*)ws, stream);
 }

@@ -126,6 +126,7 @@ SIGNATURES = {
     "frl_tcn_hot_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, F, P, S, P]),
     "frl_tcn_hot_force_generic_tiles": (c_int, [I]),
     "frl_tcn_hot_bwd_variant": (c_int, [I]),
+    "frl_decoder_mse_bwd_subgroups": (c_int, [I]),
     "frl_tcn_hot_bwd4_share": (c_int, [I, I]),
     "frl_tcn_chain_static_tiles": (c_int, [I]),
     "frl_conv3x3_bwd_data_outmask": (c_int, [P, P, I, P, P, P, I, I, I, I, I, I, I, P, S, P]),
