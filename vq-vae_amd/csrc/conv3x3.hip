@@ -163,8 +163,8 @@ __device__ __forceinline__ void c3_halo_commit(const C3Halo<T, CK, NTHR, TH, MAS
 __device__ unsigned long long* c3_dbg;       // diagnostic build only (tools/diag/c3_stamps.hip)
 #endif
 // TH: tile height (16 or 32 rows of 16 pixels); a wave owns RPW = TH / 8 consecutive rows.  TH = 32 halves the barriers / halo commits per
-// pixel, doubles the MFMA burst a prefetched halo has to hide behind, and lets four rows share each weight fragment read (16 LDS
-// fragment reads per 32 MFMAs instead of 12 per 16); the tap look-ahead keeps both weight sets but only one extra row of pixel fragments.
+// pixel, doubles the MFMA burst a prefetched halo has to hide behind, and (4 rows per wave) reads the pixel fragments of a column shift
+// once for all three tap rows: 108 LDS fragment reads per 288 MFMAs and stage, against 12 per 16 MFMAs with two rows per wave.
 template <typename T, int NF, bool EPI = false, int TH = C3F_TH, bool MASK = true>
 __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, const T* __restrict__ Xmask, int mask_act,
                                                       const typename DT<T>::frag_t* __restrict__ Wpk,
@@ -290,38 +290,39 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const T* __restrict__ X, c
           }
         }
       } else {
-        // 4 rows per wave: the weight fragments of a tap serve four rows; look-ahead = the next (tap, row)'s pixel fragments and, behind the
-        // last row of a tap, the next tap's weight fragments
-        frag_t bfr[2][NF], afr[2][4][NF];
-        auto b_load = [&](int step, int buf) {                    // step = tap * RPW + row
-          const int tap = step / RPW, t = step % RPW;
-          const int dy = tap / 3, dx = tap % 3;
-          const T* hp = halo + ((RPW * wave + t + dy) * C3_WP + px + dx) * pitch + q * kc;
+        // 4 rows per wave.  For one column shift dx the pixel fragments of the six halo rows a wave touches are read ONCE into registers and
+        // serve all three tap rows (a tap-major loop reads a pixel fragment pair per (tap, output row): 72 per stage instead of 36); the
+        // weight fragments stream through a two-deep register ring, one 16-row output block of one tap at a time.  LDS fragment reads per
+        // stage and wave: 72 + 36 = 108 instead of 144 for 288 MFMAs -- the tap loop is bound by the LDS array (256 B/clk per CU).
+        frag_t bfr[RPW + 2][NF], afr[2][NF];
+        auto a_load = [&](int step, int dx, int buf) {            // step = dy * 4 + m
+          const int dy = step >> 2, m = step & 3;
 #pragma unroll
-          for (int s = 0; s < NF; ++s) {
-            if constexpr (FE == 8) bfr[buf][s] = *reinterpret_cast<const bf16x8*>(hp + 8 * s);
-            else bfr[buf][s] = hp[s];
+          for (int s = 0; s < NF; ++s) afr[buf][s] = wl[(((dy * 3 + dx) * 4 + m) * NF + s) * 64 + lane];
+        };
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 0; r < RPW + 2; ++r) {
+            const T* hp = halo + ((RPW * wave + r) * C3_WP + px + dx) * pitch + q * kc;
+#pragma unroll
+            for (int s = 0; s < NF; ++s) {
+              if constexpr (FE == 8) bfr[r][s] = *reinterpret_cast<const bf16x8*>(hp + 8 * s);
+              else bfr[r][s] = hp[s];
+            }
           }
-        };
-        auto a_load = [&](int tap, int buf) {
+          a_load(0, dx, 0);
 #pragma unroll
-          for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int s = 0; s < NF; ++s) afr[buf][m][s] = wl[((tap * 4 + m) * NF + s) * 64 + lane];
-        };
-        a_load(0, 0);
-        b_load(0, 0);
-#pragma unroll
-        for (int step = 0; step < 9 * RPW; ++step) {
-          const int tap = step / RPW, t = step % RPW, cb = step & 1, ca = tap & 1;
-          __builtin_amdgcn_sched_barrier(0);                      // (one step of look-ahead, not more: hoisted further the fragments spill)
-          if (step + 1 < 9 * RPW) b_load(step + 1, cb ^ 1);
-          if (t == 0 && tap + 1 < 9) a_load(tap + 1, ca ^ 1);
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
+          for (int step = 0; step < 12; ++step) {
+            const int dy = step >> 2, m = step & 3;
+            __builtin_amdgcn_sched_barrier(0);                    // (one weight block of look-ahead, not more)
+            if (step + 1 < 12) a_load(step + 1, dx, (step + 1) & 1);
             if (m < nmb) {
 #pragma unroll
-              for (int s = 0; s < NF; ++s) acc[t][m] = mfma16(afr[ca][m][s], bfr[cb][s], acc[t][m]);
+              for (int s = 0; s < NF; ++s)
+#pragma unroll
+                for (int t = 0; t < RPW; ++t) acc[t][m] = mfma16(afr[step & 1][s], bfr[t + dy][s], acc[t][m]);
             }
           }
         }
