@@ -395,6 +395,11 @@ int frl_vq_assign_fwd(const void* z, const float* E, int64_t N, int K, int d, in
  * The image also holds the kernel's arrival counter and histogram accumulator (zeroed by frl_vq_prepare and left zeroed by every
  * call), so at most ONE assignment may be in flight per prepared image. */
 size_t frl_vq_prepared_bytes(int K, int d);
+/* A/B hook for the resident-codebook assignment of bf16 rows with d = 64 whose row count is a whole number of batches: nt = 1 / 2 / 4
+ * selects the streaming kernel (one 16-wave workgroup per CU, 16 * nt * 16 rows per batch, no workgroup barrier in the batch loop),
+ * 0 the kernel of round 2, -1 the default (environment variable FRL_VQ_STREAM, else the built-in choice).  Returns the previous
+ * setting; outputs are the same bit for bit (the squared-error sum up to float32 summation order). */
+int frl_vq_stream_tiles(int nt);
 int frl_vq_prepare(const float* E, int64_t N, int K, int d, int dtype, void* prep, size_t prep_bytes, frl_stream_t stream);
 int frl_vq_assign_fwd_prepared(const void* z, const float* E, void* prep /* NULL: prepare inside the call */, int64_t N, int K, int d,
                                int32_t* idx_out, void* zq_out, float* stats_out, int32_t* counts_out, int dtype, void* ws,

@@ -147,6 +147,60 @@ def test_vq_assign_every_row_is_a_tie(dtype, N, K, d, dup):
     assert torch.equal(idx2, idx) and torch.equal(zq2, zq) and torch.equal(counts2, counts) and torch.equal(stats2, stats)
 
 
+@pytest.mark.parametrize("N,K,case", [(4096, 512, "randn"), (2048, 256, "ties"), (1024, 200, "randn"), (256, 16, "ties"), (1536, 512, "dup2"),
+                                      (512, 64, "dup64"), (262144, 512, "live"), (8192, 512, "nan")])
+def test_vq_assign_streaming_kernel_matches_resident(N, K, case):
+    """The streaming assignment kernel (one 16-wave workgroup per CU, wave-local exact re-evaluation; bf16 rows of 64 channels, whole
+    batches) against the float64 arg-min and against the resident kernel of round 2: indices, z_q, histogram and the number of rows
+    re-evaluated are identical for every tile count; the squared-error sum differs by float32 summation order only.  Cases: plain
+    randn, constructed ties (duplicate code, sign-symmetric pair, exact hit), a codebook that is not a whole key group (K = 200:
+    13 code blocks), every row a tie between 2 / 64 duplicates (in-lane candidate flush), a live codebook at the full configs[1] row
+    count, rows of NaN / inf."""
+    from frl_hip import ops
+    dev = _dev()
+    d, dtype = 64, torch.bfloat16
+    g = torch.Generator().manual_seed(N + K)
+    z = torch.randn(N, d, generator=g)
+    if case.startswith("dup"):
+        dup = int(case[3:])
+        e = torch.randn(K // dup, d, generator=g).repeat_interleave(dup, dim=0).contiguous()
+    elif case == "live":
+        e = z[torch.randperm(N, generator=g)[:K]].to(dtype).float().contiguous()
+    else:
+        e = torch.randn(K, d, generator=g)
+    if case == "ties":
+        e[K - 1] = e[3]; z[5] = 0.0; e[7] = -e[2]; z[6] = e[4]
+    if case == "nan":
+        z[17] = float("nan"); z[300, 3] = float("inf"); z[4097] = float("-inf")
+    zt = z.to(dtype)
+    e_eff = e.to(dtype).float()
+    zd, ed = zt.to(dev), e.to(dev)
+    prev = ops.vq_stream_tiles(0)
+    try:
+        ref = ops.vq_assign(zd, ed)
+        if case != "nan":
+            if case.startswith("dup"):
+                want = torch.from_numpy(O.vq_argmin_np(zt.float().numpy(), e_eff[::dup].contiguous().numpy())) * dup
+            else:
+                want = torch.from_numpy(O.vq_argmin_np(zt.float().numpy(), e_eff.numpy()))
+            assert torch.equal(ref[0].cpu().long(), want)
+        for nt in (1, 2, 4):
+            ops.vq_stream_tiles(nt)
+            if N % (256 * nt):
+                continue
+            prep = ops.vq_prepare(ed, N, dtype)
+            for _ in range(2):                                           # (twice: the control block re-arms itself)
+                idx, zq, stats, counts = ops.vq_assign(zd, ed, prep)
+                assert torch.equal(idx, ref[0]), f"nt={nt}: {(idx != ref[0]).sum().item()} mismatching indices"
+                assert torch.equal(zq.view(torch.int16), ref[1].view(torch.int16)) and torch.equal(counts, ref[3])
+                assert stats[2].item() == ref[2][2].item()
+                if case != "nan":
+                    assert abs(stats[0].item() - ref[2][0].item()) <= 2e-6 * ref[2][0].item()
+                    assert abs(stats[1].item() - ref[2][1].item()) <= 1e-6 * ref[2][1].item()
+    finally:
+        ops.vq_stream_tiles(prev)
+
+
 def test_vq_golden_fixture(golden_dir):
     from frl_hip import ops
     dev = _dev()

@@ -13,7 +13,10 @@ dev = "cuda:0"
 N, K, d = 262144, 512, 64
 g = torch.Generator().manual_seed(0)
 z = torch.randn(N, d, generator=g).to(torch.bfloat16).to(dev)
-for name in ("data", "randn"):
+variants = [int(v) for v in os.environ.get("VQ_BENCH_TILES", "0,1,2,4").split(",")]
+for name, nt in [(nm, v) for nm in ("data",) for v in variants]:
+    ops.vq_stream_tiles(nt)
+    g.manual_seed(1)
     E = z[torch.randperm(N, generator=g)[:K].to(dev)].float().contiguous() if name == "data" else torch.randn(K, d, generator=g).to(dev)
     prep = ops.vq_prepare(E, N, torch.bfloat16)
     for _ in range(3):
@@ -28,5 +31,5 @@ for name in ("data", "randn"):
         ts.append(a.elapsed_time(b) * 1e3)
     ts.sort()
     nbytes = N * (2 * d * 2 + 4) + K * d * 4
-    print(json.dumps({"codebook": name, "us_median": round(ts[15], 1), "us_min": round(ts[0], 1), "GB/s_at_min": round(nbytes / ts[0] / 1e3, 1),
+    print(json.dumps({"codebook": name, "stream_tiles": nt, "us_median": round(ts[15], 1), "us_min": round(ts[0], 1), "GB/s_at_min": round(nbytes / ts[0] / 1e3, 1),
                       "frac_of_8TB/s": round(nbytes / ts[0] / 1e3 / 8000, 3), "rows_reevaluated": float(stats[2]) / N, "perplexity": round(float(stats[1]), 1)}), flush=True)

@@ -20,6 +20,7 @@
 #include "frl_host.hpp"
 #include "frl_reduce.hpp"
 #include <math.h>
+#include <stdlib.h>
 
 #define VQ_IDX_BITS 7
 #define VQ_IDX_MASK 127u        // keys carry a 7-bit index inside groups of 128 codes (8 MFMA row blocks)
@@ -861,6 +862,439 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 1)) void vq_assign_resident
 }
 
 // ---------------------------------------------------------------------------------------------
+// Streaming form of the resident-codebook assignment for the measured shape (bf16 rows of d = 64 channels, K <= 512): ONE 16-wave
+// workgroup per CU keeps ONE copy of the codebook image and loops over batches of 16 * NT * 16 rows.  Nothing inside the loop waits
+// for the workgroup: every wave requests its rows of the NEXT batch before it scores the current ones, its z_q / index stores drain
+// behind the next batch's scoring, and a tile that holds ambiguous rows is resolved by the wave that owns it (the rows go to a
+// wave-private LDS scratch, the tile is re-scored against the whole image, codes under the row's limit are evaluated in float64
+// in-lane: the arithmetic of the resident kernel's sequential path, so indices and z_q are the same bit for bit).  Row results and the
+// per-wave squared-error partials depend on the row-to-wave mapping only, never on timing.
+// ---------------------------------------------------------------------------------------------
+#define VQS_NW 16
+#define VQS_ZP 72            // pitch (bf16) of a scratch row: 144 B keeps the 16-byte reads of different rows on different banks
+#define VQS_GRP 16           // code blocks per key group: the 7-bit index is (block in group) * 4 + accumulator row, the lane adds its quarter
+
+// scores CNT (FULL: VQS_GRP, compile-time) code blocks from mb0 on against NT row tiles; (c1, c2) = smallest / second smallest key per tile
+template <int NT, bool FULL>
+__device__ __forceinline__ void vqs_score_group(const bf16x8* __restrict__ wl, const float* __restrict__ enl, int lane, int kc, int mb0, int cnt,
+                                                const LQTile<bf16, 2> (&z)[NT], unsigned (&c1)[NT], unsigned (&c2)[NT]) {
+  const unsigned maskv = ~VQ_IDX_MASK;
+  auto block = [&](int mb, int j) {
+    const f32x4 en4 = *reinterpret_cast<const f32x4*>(enl + mb * 16 + 4 * kc);
+    const bf16x8 a0 = wl[(mb * 2 + 0) * 64 + lane], a1 = wl[(mb * 2 + 1) * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x4 acc = mfma16(a0, z[t].f[0], en4);
+      acc = mfma16(a1, z[t].f[1], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // (written in C, not as inline assembly: the first reader of a matrix-core result must be an instruction the compiler sees,
+        // or the wait states between v_mfma and the read are not inserted)
+        const unsigned key = (__float_as_uint(acc[r]) & maskv) | (unsigned)(4 * j + r);
+        asm("v_med3_f32 %0, %1, %2, %3" : "=v"(c2[t]) : "v"(c1[t]), "v"(c2[t]), "v"(key));   // runner-up (c1 <= c2)
+        asm("v_min_f32 %0, %1, %2" : "=v"(c1[t]) : "v"(c1[t]), "v"(key));
+      }
+    }
+  };
+  if constexpr (FULL) {
+#pragma unroll
+    for (int j = 0; j < VQS_GRP; ++j) block(mb0 + j, j);
+  } else {
+    for (int j = 0; j < cnt; ++j) block(mb0 + j, j);
+  }
+}
+
+// Row loads of the streaming kernel are issued from inline assembly, so that the compiler's s_waitcnt insertion does not see them: on
+// gfx9 loads and stores share vmcnt, and across the batch loop's back edge the compiler's count for "the rows of this batch have
+// arrived" also waited for the z_q / index stores the previous batch had just issued (store latency exposed once per batch).  The wait
+// is placed by hand instead (vqs_wait): the two loads of a tile retire in issue order, and exactly CNT vector-memory operations (the
+// stores of the batch in between) were issued behind the rows being waited for.  The registers are in / out operands of the wait, so no
+// use of them can be scheduled above it.
+__device__ __forceinline__ void vqs_load_row(LQTile<bf16, 2>& t, const bf16* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t.f[0]) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(t.f[1]) : "v"(p) : "memory");
+}
+template <int NT, int CNT>
+__device__ __forceinline__ void vqs_wait(LQTile<bf16, 2> (&b)[NT]) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0].f[0]), "+v"(b[0].f[1]) : "n"(CNT) : "memory");
+#pragma unroll
+  for (int t = 1; t < NT; ++t) asm volatile("" : "+v"(b[t].f[0]), "+v"(b[t].f[1]) : : "memory");
+}
+
+// exact arg-min of the rows of one 16-row tile by the wave that holds it: the tile (lane-quarter fragments zt; this lane's row also lies
+// in LDS at zrow) is re-scored against the whole image, every code whose score is <= the row's limit is evaluated in float64 in-lane
+// (up to two pending per lane, flushed together), smallest code among the minima.  The sequential path of the resident kernel.
+__device__ __forceinline__ int vqs_resolve_inlane(const LQTile<bf16, 2>& zt, const bf16* __restrict__ zrow, const bf16x8* __restrict__ wl,
+                                                  const float* __restrict__ enl, int nmb, int K, int lane, int kc, bool mine, float lm) {
+  double bestd = 1.0e300;
+  int bk = 0x7fffffff, p0 = -1, p1 = -1;
+  auto flush = [&]() {
+    if (p0 >= 0) {
+      const double d0 = vq_exact_lds<2>(zrow, wl, p0, 64);
+      if (d0 < bestd || (d0 == bestd && p0 < bk)) { bestd = d0; bk = p0; }
+      if (p1 >= 0) {
+        const double d1 = vq_exact_lds<2>(zrow, wl, p1, 64);
+        if (d1 < bestd || (d1 == bestd && p1 < bk)) { bestd = d1; bk = p1; }
+      }
+    }
+    p0 = p1 = -1;
+  };
+  for (int mb = 0; mb < nmb; ++mb) {
+    f32x4 acc = *reinterpret_cast<const f32x4*>(enl + mb * 16 + 4 * kc);
+    acc = mfma16(wl[(mb * 2 + 0) * 64 + lane], zt.f[0], acc);
+    acc = mfma16(wl[(mb * 2 + 1) * 64 + lane], zt.f[1], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cd = mb * 16 + 4 * kc + r;
+      const bool hit = mine && acc[r] <= lm && cd < K;
+      if (__builtin_amdgcn_ballot_w64(hit && p1 >= 0) != 0ull) flush();       // a lane with both slots taken: evaluate all pending
+      if (hit) { if (p0 < 0) p0 = cd; else p1 = cd; }
+    }
+  }
+  flush();
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    const double ob = __shfl_xor(bestd, off, 64);
+    const int okk = __shfl_xor(bk, off, 64);
+    if (ob < bestd || (ob == bestd && okk < bk)) { bestd = ob; bk = okk; }
+  }
+  if ((unsigned)bk >= (unsigned)K) bk = 0;                         // no candidate at all (NaN row): argmin of an all-NaN row is 0
+  return bk;
+}
+
+#define VQS_CAP 8            // ambiguous rows per wave whose vectors are kept in LDS for the joint pass behind the batch loop (16 * 8 = VQ_FAST_ROWS)
+#define VQS_CAND (VQS_NW * 64)
+template <int NT>
+__global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
+    const bf16* __restrict__ Z, const float* __restrict__ en_g, int64_t N, int K, int Kc, int32_t* __restrict__ idx_out,
+    bf16* __restrict__ zq_out, float* __restrict__ partial /*[grid*NW]*/, const bf16x8* __restrict__ pk, VqCtl* __restrict__ ctl,
+    int32_t* __restrict__ counts_out, float* __restrict__ stats_out) {
+  constexpr int NF = 2, q = 16, d = 64, NW = VQS_NW;
+  constexpr int BATCH = NW * NT * 16;
+  static_assert(NW * VQS_CAP <= VQ_FAST_ROWS, "parked rows of a workgroup");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16x8* wl = reinterpret_cast<bf16x8*>(smem);                                               // [Kc/16][NF][64]
+  float* enl = reinterpret_cast<float*>(smem + (size_t)(Kc / 16) * NF * 64 * sizeof(bf16x8)); // [Kc] ||e||^2 (3e38 beyond K)
+  int* hist = reinterpret_cast<int*>(enl + Kc);                                               // [K]
+  int* misc = hist + ((K + 3) & ~3);          // [0] rows resolved, [1] candidates, [17] last flag, [18..18+NW) f32 maxima, [34..34+NW) rows parked per wave
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(misc + 64);                // [VQ_FAST_ROWS] float64 bits of the minimum
+  int* bestk = reinterpret_cast<int*>(best + VQ_FAST_ROWS);                                   // [VQ_FAST_ROWS]
+  int* plist = bestk + VQ_FAST_ROWS;                                                          // [VQ_FAST_ROWS] parked rows in (wave, slot) order -> entry
+  unsigned* prow = reinterpret_cast<unsigned*>(plist + VQ_FAST_ROWS);                         // [NW * CAP] row
+  float* plim = reinterpret_cast<float*>(prow + NW * VQS_CAP);                                // [NW * CAP] limit
+  int* cand = reinterpret_cast<int*>(plim + NW * VQS_CAP);                                    // [VQS_CAND] (list index << 16) | code
+  bf16* zdef = reinterpret_cast<bf16*>(cand + VQS_CAND);                                      // [NW * CAP][VQS_ZP] vectors of the parked rows
+  bf16* zpark = zdef + NW * VQS_CAP * VQS_ZP;                                                 // [NW][16][VQS_ZP] wave-private tile scratch (overflow path)
+  int32_t* counts_acc = reinterpret_cast<int32_t*>(ctl + 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vx = lane & 15, kc = lane >> 4;
+  const int nmb = Kc / 16;
+  const int64_t nbatch = N / BATCH;                                // (the host checks N % BATCH == 0 and launches at most nbatch workgroups)
+  LQTile<bf16, NF> bufA[NT], bufB[NT];
+  auto load_batch = [&](LQTile<bf16, NF> (&dst)[NT], int64_t b) {
+    const int64_t r0 = b * BATCH + (int64_t)wave * (NT * 16);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) vqs_load_row(dst[t], Z + (r0 + t * 16 + vx) * d + q * kc);
+  };
+  load_batch(bufA, blockIdx.x);
+  // ---- once per workgroup: codebook image, norms, their maximum, cleared histogram / lists ----
+  for (int i = tid; i < nmb * NF * 64; i += NW * 64) wl[i] = pk[i];
+  float enmax;
+  {
+    float m = 0.f;
+    for (int i = tid; i < Kc; i += NW * 64) {
+      const float v = i < K ? en_g[i] : 3.0e38f;
+      enl[i] = v;
+      if (i < K) m = fmaxf(m, v);
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) misc[18 + wave] = __float_as_int(m);
+  }
+  for (int k = tid; k < K; k += NW * 64) hist[k] = 0;
+  if (tid < VQ_FAST_ROWS) { best[tid] = ~0ull; bestk[tid] = 0x7fffffff; }
+  if (tid < 2) misc[tid] = 0;
+  __syncthreads();
+  {
+    float m = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) m = fmaxf(m, __int_as_float(misc[18 + w]));
+    enmax = m;
+  }
+  const float err_rel = (float)(4 * q + 8) * 1.1920929e-7f;            // (d_pad+8) * 2^-23: f32 accumulation of exact products
+  const float thr_rel = (3.0517578125e-5f + 2.f * err_rel) * 1.001953125f;   // 2^-15: key truncation of both scores, + 2*err, + margin
+  const float enroot = sqrtf(enmax);
+  float sq_acc = 0.f;
+  int n_resolved = 0, cnt_w = 0;                                   // (wave-uniform) rows re-evaluated / rows parked in this wave's LDS segment
+  bf16* zp = zpark + wave * 16 * VQS_ZP;
+
+  // one batch: `cur` holds its rows (requested one batch earlier), `nxt` receives the rows of the batch after it
+  auto step = [&](LQTile<bf16, NF> (&cur)[NT], LQTile<bf16, NF> (&nxt)[NT], int64_t batch) {
+    const int64_t v0 = batch * BATCH + (int64_t)wave * (NT * 16);
+    // the rows of this batch were requested a whole batch ago; behind them only the 3 * NT stores of the previous batch were issued
+    // (every vector-memory operation of a step is issued unconditionally; the last step requests its own rows again: an L2 hit)
+    vqs_wait<NT, 3 * NT>(cur);
+    load_batch(nxt, batch + (int64_t)gridDim.x < nbatch ? batch + gridDim.x : batch);
+    float thr[NT];
+    unsigned g1[NT], g2[NT];
+    int gc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float zn = 0.f;
+#pragma unroll
+      for (int s = 0; s < NF; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float v = (float)cur[t].f[s][e]; zn = fmaf(v, v, zn); }
+      zn += __shfl_xor(zn, 16, 64);
+      zn += __shfl_xor(zn, 32, 64);
+      const float sroot = sqrtf(zn) + enroot;                      // |score| and every partial sum <= (||z|| + ||e||max)^2
+      thr[t] = sroot * sroot * thr_rel + 1e-37f;
+      g1[t] = 0x7F800000u; g2[t] = 0x7F800000u; gc[t] = 0;         // +inf
+    }
+    for (int g0 = 0; g0 < nmb; g0 += VQS_GRP) {
+      unsigned c1[NT], c2[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { c1[t] = 0x7F800000u; c2[t] = 0x7F800000u; }
+      if (g0 + VQS_GRP <= nmb) vqs_score_group<NT, true>(wl, enl, lane, kc, g0, VQS_GRP, cur, c1, c2);
+      else vqs_score_group<NT, false>(wl, enl, lane, kc, g0, nmb - g0, cur, c1, c2);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {                               // fold the group into the running (best, runner-up, group)
+        const float a1 = __uint_as_float(g1[t]), a2 = __uint_as_float(g2[t]), b1 = __uint_as_float(c1[t]), b2 = __uint_as_float(c2[t]);
+        const float hi = fmaxf(a1, b1), lo2 = fminf(a2, b2);
+        g2[t] = __float_as_uint(fminf(hi, lo2));
+        if (b1 < a1) { g1[t] = c1[t]; gc[t] = g0; }
+      }
+    }
+    // ---- min-reduce over the 4 lane groups that share a row (code = block * 16 + 4 * quarter + accumulator row, the quarter is the
+    // lane's own); ambiguity test; z_q, squared error, histogram ----
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      int cd1 = (gc[t] + (int)((g1[t] & VQ_IDX_MASK) >> 2)) * 16 + 4 * kc + (int)(g1[t] & 3u);
+#pragma unroll
+      for (int off = 16; off <= 32; off <<= 1) {
+        const unsigned o1 = __shfl_xor(g1[t], off, 64), o2 = __shfl_xor(g2[t], off, 64);
+        const int oc = __shfl_xor(cd1, off, 64);
+        const float a1 = __uint_as_float(g1[t] & ~VQ_IDX_MASK), a2 = __uint_as_float(g2[t]), b1 = __uint_as_float(o1 & ~VQ_IDX_MASK), b2 = __uint_as_float(o2);
+        const float hi = fmaxf(__uint_as_float(g1[t]), __uint_as_float(o1)), lo2 = fminf(a2, b2);
+        g2[t] = __float_as_uint(fminf(hi, lo2));
+        if (b1 < a1 || (b1 == a1 && oc < cd1)) { g1[t] = o1; cd1 = oc; }
+      }
+      const int64_t row = v0 + t * 16 + vx;
+      int code = cd1;
+      const float s1 = __uint_as_float(g1[t] & ~VQ_IDX_MASK), s2 = __uint_as_float(g2[t] & ~VQ_IDX_MASK);
+      const bool amb = !((s2 - s1) > thr[t]) || (unsigned)code >= (unsigned)K;   // also catches NaN / inf rows
+      const float lm = s1 + thr[t] + 2.3841858e-7f * fabsf(s1);
+      const unsigned long long pm = __builtin_amdgcn_ballot_w64(amb && kc == 0);
+      bool parked = false;
+      if (pm != 0ull) {                                            // (wave-uniform) this tile holds rows to re-evaluate exactly
+        const int np = __builtin_popcountll(pm);
+        if (cnt_w + np <= VQS_CAP) {
+          // the usual case (0.3-0.7 % of the rows): vector, row and limit go to the wave's LDS segment in row order, the whole workgroup
+          // resolves them behind the batch loop; the provisional z_q / index below are stored all the same (the store count per
+          // step stays fixed) and overwritten there
+          if (amb) {
+            const int e = wave * VQS_CAP + cnt_w + __builtin_popcountll(pm & ((1ull << vx) - 1ull));
+            *reinterpret_cast<bf16x8*>(zdef + e * VQS_ZP + q * kc) = cur[t].f[0];
+            *reinterpret_cast<bf16x8*>(zdef + e * VQS_ZP + q * kc + 8) = cur[t].f[1];
+            if (kc == 0) { prow[e] = (unsigned)row; plim[e] = lm; }
+          }
+          cnt_w += np;
+          parked = amb;
+        } else {
+          // segment full (constructed inputs: every row a tie): the wave resolves the tile on its own, no other wave is waited for
+          *reinterpret_cast<bf16x8*>(zp + vx * VQS_ZP + q * kc) = cur[t].f[0];
+          *reinterpret_cast<bf16x8*>(zp + vx * VQS_ZP + q * kc + 8) = cur[t].f[1];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private scratch: LDS operations of one wave complete in order
+          const int bk = vqs_resolve_inlane(cur[t], zp + vx * VQS_ZP, wl, enl, nmb, K, lane, kc, amb, lm);
+          if (amb) code = bk;
+        }
+        n_resolved += np;
+      }
+      {
+        bf16* zo = zq_out + row * (int64_t)d + q * kc;
+        float sl = 0.f;
+#pragma unroll
+        for (int s = 0; s < NF; ++s) {                             // e (rounded to bf16) = -0.5 * the packed -2e: exact
+          const bf16x8 pv = wl[((code >> 4) * NF + s) * 64 + (code & 15) + 16 * kc];
+          bf16x8 ev;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = -0.5f * (float)pv[e];
+            ev[e] = (bf16)f;
+            const float df = (float)cur[t].f[s][e] - f;
+            sl = fmaf(df, df, sl);
+          }
+          *reinterpret_cast<bf16x8*>(zo + 8 * s) = ev;
+        }
+        idx_out[row] = code;                                       // (the four lanes of a row store the same word)
+        if (!parked) {
+          sq_acc += sl;
+          if (kc == 0) atomicAdd(&hist[code], 1);
+        }
+      }
+    }
+  };
+  for (int64_t batch = blockIdx.x; batch < nbatch; batch += 2 * (int64_t)gridDim.x) {
+    step(bufA, bufB, batch);
+    if (batch + (int64_t)gridDim.x < nbatch) step(bufB, bufA, batch + gridDim.x);
+  }
+  // the last step's (redundant) row loads are still in flight and the compiler does not know it: both buffers stay live up to this wait,
+  // so their registers cannot be handed to the tail's variables before the loads have landed.  It also orders the provisional stores of
+  // the parked rows before the final ones below.
+  vqs_wait<NT, 0>(bufA);
+  vqs_wait<NT, 0>(bufB);
+  // ---- the parked rows of the whole workgroup (<= 8 per wave, in (wave, slot) = row order): every wave re-scores them against its share
+  // of the code blocks, one lane per candidate evaluates the float64 distance, LDS integer atomics keep the minimum and then the
+  // smallest code among the minima -- the all-wave pass of the resident kernel ----
+  if (lane == 0) misc[34 + wave] = cnt_w;
+  __syncthreads();
+  int pbase = 0, npark = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) { const int c = misc[34 + w]; if (w < wave) pbase += c; npark += c; }
+  if (npark > 0) {                                                  // (uniform)
+    if (lane < cnt_w) plist[pbase + lane] = wave * VQS_CAP + lane;
+    __syncthreads();
+    const int mb0 = (wave * nmb) / NW, mb1 = ((wave + 1) * nmb) / NW;
+    for (int t0 = 0; t0 < npark; t0 += 16) {
+      const int li = t0 + vx;
+      const bool valid = li < npark;
+      const int e = plist[valid ? li : t0];
+      const float lm = plim[e];
+      LQTile<bf16, NF> zr;
+      zr.f[0] = *reinterpret_cast<const bf16x8*>(zdef + e * VQS_ZP + q * kc);
+      zr.f[1] = *reinterpret_cast<const bf16x8*>(zdef + e * VQS_ZP + q * kc + 8);
+      for (int mb = mb0; mb < mb1; ++mb) {
+        f32x4 acc = *reinterpret_cast<const f32x4*>(enl + mb * 16 + 4 * kc);
+        acc = mfma16(wl[(mb * NF + 0) * 64 + lane], zr.f[0], acc);
+        acc = mfma16(wl[(mb * NF + 1) * 64 + lane], zr.f[1], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cd = mb * 16 + 4 * kc + r;
+          if (valid && acc[r] <= lm && cd < K) {
+            const int pos = atomicAdd(&misc[1], 1);
+            if (pos < VQS_CAND) cand[pos] = (li << 16) | cd;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int ncand = misc[1];
+    if (ncand <= VQS_CAND) {                                         // (uniform)
+      int li = 0, cd = 0;
+      unsigned long long bits = ~0ull;
+      if (tid < ncand) {
+        const int cv = cand[tid];
+        li = cv >> 16; cd = cv & 0xffff;
+        bits = (unsigned long long)__double_as_longlong(vq_exact_lds<NF>(zdef + plist[li] * VQS_ZP, wl, cd, d));
+        __hip_atomic_fetch_min(&best[li], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      __syncthreads();
+      if (tid < ncand && bits == best[li]) __hip_atomic_fetch_min(&bestk[li], cd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __syncthreads();
+      const int j = tid & 15;                                        // outputs of the resolved rows: 16 lanes per row
+      for (int li2 = tid >> 4; li2 < npark; li2 += NW * 4) {
+        int bk = bestk[li2];
+        if ((unsigned)bk >= (unsigned)K) bk = 0;                     // no candidate at all (NaN row): argmin of an all-NaN row is 0
+        const int e = plist[li2];
+        const int64_t row = (int64_t)prow[e];
+        for (int ch = j; ch < d; ch += 16) {
+          const float ev = -0.5f * (float)wl[((bk >> 4) * NF + ((ch % q) >> 3)) * 64 + (bk & 15) + 16 * (ch / q)][ch & 7];
+          const float zv = (float)zdef[e * VQS_ZP + ch];
+          zq_out[row * (int64_t)d + ch] = (bf16)ev;
+          const float df = zv - ev;
+          sq_acc = fmaf(df, df, sq_acc);
+        }
+        if (j == 0) { idx_out[row] = bk; atomicAdd(&hist[bk], 1); }
+      }
+    } else {
+      // more candidates than threads (constructed inputs): one wave per tile of 16 parked rows, candidates evaluated in-lane
+      for (int t0 = wave * 16; t0 < npark; t0 += NW * 16) {
+        const int li = t0 + vx;
+        const bool valid = li < npark;
+        const int e = plist[valid ? li : t0];
+        LQTile<bf16, NF> zr;
+        zr.f[0] = *reinterpret_cast<const bf16x8*>(zdef + e * VQS_ZP + q * kc);
+        zr.f[1] = *reinterpret_cast<const bf16x8*>(zdef + e * VQS_ZP + q * kc + 8);
+        const int bk = vqs_resolve_inlane(zr, zdef + e * VQS_ZP, wl, enl, nmb, K, lane, kc, valid, plim[e]);
+        if (valid) {
+          const int64_t row = (int64_t)prow[e];
+          bf16* zo = zq_out + row * (int64_t)d + q * kc;
+#pragma unroll
+          for (int s = 0; s < NF; ++s) {
+            const bf16x8 pv = wl[((bk >> 4) * NF + s) * 64 + (bk & 15) + 16 * kc];
+            bf16x8 ev;
+#pragma unroll
+            for (int e2 = 0; e2 < 8; ++e2) {
+              const float f = -0.5f * (float)pv[e2];
+              ev[e2] = (bf16)f;
+              const float df = (float)zr.f[s][e2] - f;
+              sq_acc = fmaf(df, df, sq_acc);
+            }
+            *reinterpret_cast<bf16x8*>(zo + 8 * s) = ev;
+          }
+          if (kc == 0) { idx_out[row] = bk; atomicAdd(&hist[bk], 1); }
+        }
+      }
+    }
+  }
+  // ---- per-workgroup outputs: wave partials of the squared error; histogram by integer atomics (order-independent) ----
+  const float ws_ = wave_sum(sq_acc);
+  if (lane == 0) {
+    partial[blockIdx.x * NW + wave] = ws_;
+    if (n_resolved) atomicAdd(&misc[0], n_resolved);
+  }
+  __syncthreads();
+  for (int k = tid; k < K; k += NW * 64) {
+    const int h = hist[k];
+    if (h) atomicAdd(&counts_acc[k], h);
+  }
+  if (tid == 0 && misc[0]) atomicAdd(&ctl->namb, misc[0]);
+  // publish (partials by plain stores, counts by atomics), then take a ticket; the last workgroup folds everything
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ticket = __hip_atomic_fetch_add(&ctl->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    misc[17] = (ticket == (int)gridDim.x - 1) ? 1 : 0;
+    if (ticket == (int)gridDim.x - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  const bool last = misc[17] != 0;
+  __syncthreads();
+  if (last) {
+    double* red = reinterpret_cast<double*>(smem);                  // (the codebook fragments are no longer needed)
+    const int npartial = (int)gridDim.x * NW;
+    double sp = 0.0;
+    for (int i = tid; i < npartial; i += NW * 64) sp += (double)__hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double hp = 0.0;
+    for (int k = tid; k < K; k += NW * 64) {
+      const int c = __hip_atomic_load(&counts_acc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      counts_out[k] = c;
+      __hip_atomic_store(&counts_acc[k], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // clean for the next call
+      const double p = (double)c / (double)N;
+      hp += p * log(p + 1e-10);
+    }
+    sp = wave_sum_d(sp);
+    hp = wave_sum_d(hp);
+    if (lane == 0) { red[wave] = sp; red[NW + wave] = hp; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < NW; ++w) { red[0] += red[w]; red[NW] += red[NW + w]; }     // fixed order
+      stats_out[0] = (float)red[0];
+      stats_out[1] = (float)exp(-red[NW]);
+      stats_out[2] = (float)__hip_atomic_load(&ctl->namb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      stats_out[3] = (float)(red[0] / ((double)N * (double)d));   // mean squared error (the two VQ loss terms)
+      __hip_atomic_store(&ctl->namb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ctl->done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Exact re-evaluation of the flagged rows of the multi-chunk path, 16 rows per workgroup (8 waves, each with its share of the code
 // blocks, merged in wave order): the rows are re-scored against the WHOLE packed
 // image on the matrix cores (fragments streamed from L2: 2 MB per tile at K = 8192, d = 128, instead of the 4 MB float32 codebook per
@@ -1340,6 +1774,16 @@ static int launch_vq_prepare(const float* E, int64_t N, int K, int d, char* prep
   return frl_check_launch("vq_prepare");
 }
 
+static int g_vq_stream_tiles = -1;    // frl_vq_stream_tiles(): -1 = the FRL_VQ_STREAM environment variable, else VQ_STREAM_DEFAULT
+static int vq_stream_tiles();
+#ifndef VQ_STREAM_DEFAULT
+#define VQ_STREAM_DEFAULT 1   // tiles per wave and batch of the streaming kernel when FRL_VQ_STREAM is unset (0: resident kernel)
+#endif
+static int vq_stream_tiles() {
+  if (g_vq_stream_tiles >= 0) return g_vq_stream_tiles;
+  static const int env = [] { const char* e = getenv("FRL_VQ_STREAM"); return e ? atoi(e) : VQ_STREAM_DEFAULT; }();
+  return env;
+}
 #ifndef VQ_RES_NT
 #define VQ_RES_NT 4        // 16-row tiles per wave and batch of the resident kernel
 #endif
@@ -1361,6 +1805,31 @@ static int launch_vq(const void* z, const float* E, char* prep, int64_t N, int K
   }
   const float* en = (const float*)(prep + P.en);
   const frag_t* pk = (const frag_t*)(prep + P.pack);
+  if constexpr (sizeof(T) == 2 && NF == 2) {
+    // streaming form (one 16-wave workgroup per CU, no workgroup barrier in the batch loop); FRL_VQ_STREAM=0 selects the older kernel,
+    // FRL_VQ_STREAM=1 / 2 / 4 the 16-row tiles per wave and batch (A/B hook, read once)
+    const int stream_nt = vq_stream_tiles();
+    const int nt = stream_nt >= 4 ? 4 : (stream_nt >= 2 ? 2 : 1);
+    const int batch = VQS_NW * nt * 16;
+    if (resident && stream_nt > 0 && d == 64 && (Kc & 15) == 0 && N % batch == 0 && N < ((int64_t)1 << 32)) {   // whole batches only: no row guards in the kernel
+      const int64_t nb = (N + batch - 1) / batch;
+      const int grid_s = (int)(nb < 256 ? nb : 256);
+      const size_t lds = (size_t)(Kc / 16) * NF * 64 * sizeof(frag_t) + (size_t)Kc * 4 + (size_t)((K + 3) & ~3) * 4 + 64 * 4 +
+                         (size_t)VQ_FAST_ROWS * 16 + (size_t)VQS_NW * VQS_CAP * 8 + (size_t)VQS_CAND * 4 +
+                         (size_t)VQS_NW * (VQS_CAP + 16) * VQS_ZP * sizeof(T);
+      if (lds > 160 * 1024) return frl_fail(-3, "vq_assign: LDS budget exceeded");
+#define VQ_GOS(NT_)                                                                                                                \
+  do {                                                                                                                             \
+    auto kern = vq_assign_stream_kernel<NT_>;                                                                                      \
+    if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+    FRL_LAUNCH_AS("vq_assign_kernel", kern, dim3(grid_s), dim3(64 * VQS_NW), lds, st, (const bf16*)z, en, N, K, Kc, idx, (bf16*)zq,  \
+                  (float*)(ws + L.partial), (const bf16x8*)pk, (VqCtl*)(prep + P.ctl), counts, stats);                              \
+  } while (0)
+      if (nt == 4) VQ_GOS(4); else if (nt == 2) VQ_GOS(2); else VQ_GOS(1);
+#undef VQ_GOS
+      return frl_check_launch("vq_assign");
+    }
+  }
   if (resident) {
     // image | norms | histogram | per-row minima | parked rows | candidates | misc; the statistics fold of the last workgroup reuses the front
     const int nwr = (nw == 8 && NF <= (sizeof(T) == 2 ? 2 : 4)) ? 8 : 4;  // 8 waves x 4 tiles only where the tiles fit the 128-register budget
@@ -1442,6 +1911,14 @@ __global__ __launch_bounds__(64) void vq_revive_kernel(float* __restrict__ E, co
 }
 
 extern "C" {
+
+// A/B hook: 16-row tiles per wave and batch of the streaming assignment kernel (1, 2 or 4), 0 = the resident kernel of round 2,
+// -1 = back to the default (FRL_VQ_STREAM, else the built-in choice).  Returns the previous setting.  Results are identical either way.
+int frl_vq_stream_tiles(int nt) {
+  const int prev = g_vq_stream_tiles;
+  g_vq_stream_tiles = nt < 0 ? -1 : nt;
+  return prev;
+}
 
 size_t frl_vq_workspace_bytes(int64_t N, int K, int d) {
   const VqLayout L = vq_layout(N, K, d);

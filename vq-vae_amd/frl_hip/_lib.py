@@ -51,6 +51,7 @@ SIGNATURES = {
     "frl_vq_assign_fwd": (c_int, [P, P, L, I, I, P, P, P, P, I, P, S, P]),
     "frl_vq_prepared_bytes": (S, [I, I]),
     "frl_vq_prepare": (c_int, [P, L, I, I, I, P, S, P]),
+    "frl_vq_stream_tiles": (c_int, [I]),
     "frl_vq_assign_fwd_prepared": (c_int, [P, P, P, L, I, I, P, P, P, P, I, P, S, P]),
     "frl_vq_bwd": (c_int, [P, P, P, P, P, P, P, F, L, I, I, P, P, P, I, P, S, P]),
     "frl_vq_ema_update": (c_int, [P, P, I, I, F, F, P, P, P, P, P]),

@@ -320,6 +320,12 @@ conv1x1_bwd_weight = _timed("conv1x1_bwd_weight")(_conv1x1_bwd_weight_impl)
 # ----------------------------------------------------------------------------------------------
 # vector quantizer (csrc/vq.hip)
 # ----------------------------------------------------------------------------------------------
+def vq_stream_tiles(nt: int) -> int:
+    """A/B hook (include/frl_hip.h: frl_vq_stream_tiles): tiles per wave and batch of the streaming assignment kernel, 0 = the resident
+    kernel, -1 = default.  Returns the previous setting."""
+    return int(_lib.load().frl_vq_stream_tiles(int(nt)))
+
+
 @_timed("vq_prepare")
 def vq_prepare(codebook: torch.Tensor, n_rows: int, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Prepared image of the codebook (norms + packed MFMA fragments) for `vq_assign(..., prep=)`; valid until the codebook changes."""
