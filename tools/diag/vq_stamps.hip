@@ -8,6 +8,8 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 int main(int argc, char** argv) {
   const int64_t N = 262144; const int K = argc > 1 ? atoi(argv[1]) : 512, d = 64;
+  const int G = argc > 2 ? atoi(argv[2]) : 512;          // workgroups of the kernel variant (512: resident, 256: streaming)
+  if (argc > 3) frl_vq_stream_tiles(atoi(argv[3]));
   std::mt19937 rng(7); std::normal_distribution<float> nd(0.f, 1.f);
   std::vector<bf16> hz(N * d); for (auto& v : hz) v = (bf16)nd(rng);
   std::vector<float> he((size_t)K * d); for (auto& v : he) v = nd(rng);
@@ -29,17 +31,17 @@ int main(int argc, char** argv) {
   }
   { float st[4]; CK(hipMemcpy(st, stats, 16, hipMemcpyDeviceToHost)); printf("stats: sqerr %.6e perplexity %.4f re-evaluated %.0f\n", st[0], st[1], st[2]); }
   std::vector<unsigned long long> h(512 * 130); CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-  const char* nm[7] = {"z load + norms", "-", "image / norms fill (once)", "main loop", "epilogue", "park + exact re-evaluation", "partials, atomics, ticket, statistics"};
+  const char* nm[7] = {"wait for rows / z load + norms", "store drain (streaming)", "image / norms fill (once)", "main loop", "epilogue", "park + exact re-evaluation", "partials, atomics, ticket, statistics"};
   double tot = 0;
-  for (int ph = 0; ph < 7; ++ph) { double s = 0; int nz = 0; for (int b = 0; b < 512; ++b) for (int w = 0; w < 16; ++w) { const double v = (double)h[(size_t)b * 128 + w * 8 + ph]; s += v; nz += h[(size_t)b * 128 + w * 8 + 3] != 0; } s /= nz; tot += s; printf("phase %d %-28s %9.0f cycles per wave (whole kernel)\n", ph, nm[ph], s); }
+  for (int ph = 0; ph < 7; ++ph) { double s = 0; int nz = 0; for (int b = 0; b < G; ++b) for (int w = 0; w < 16; ++w) { const double v = (double)h[(size_t)b * 128 + w * 8 + ph]; s += v; nz += h[(size_t)b * 128 + w * 8 + 3] != 0; } s /= nz; tot += s; printf("phase %d %-28s %9.0f cycles per wave (whole kernel)\n", ph, nm[ph], s); }
   printf("total %.0f cycles per wave\n", tot);
   {  // workgroup lifetimes in s_memtime ticks and in 100 MHz wall-clock ticks
     double sm = 0, sw = 0; std::vector<double> life;
-    for (int b = 0; b < 512; ++b) { sm += (double)h[512 * 128 + 2 * b]; sw += (double)h[512 * 128 + 2 * b + 1]; life.push_back((double)h[512 * 128 + 2 * b + 1] * 0.01); }
+    for (int b = 0; b < G; ++b) { sm += (double)h[G * 128 + 2 * b]; sw += (double)h[G * 128 + 2 * b + 1]; life.push_back((double)h[G * 128 + 2 * b + 1] * 0.01); }
     std::sort(life.begin(), life.end());
-    printf("workgroup lifetime: mean %.0f s_memtime ticks = %.2f us wall (=> %.1f MHz tick rate); p10 %.2f p50 %.2f p90 %.2f max %.2f us\n", sm / 512, sw / 512 * 0.01, sm / sw * 100.0,
-           life[51], life[256], life[460], life[511]);
-    for (int ph = 0; ph < 7; ++ph) { double mx = 0; for (int b = 0; b < 512; ++b) for (int w = 0; w < 8; ++w) mx = std::max(mx, (double)h[(size_t)b * 128 + w * 8 + ph]); printf("phase %d max over waves %9.0f\n", ph, mx); }
+    printf("workgroup lifetime: mean %.0f s_memtime ticks = %.2f us wall (=> %.1f MHz tick rate); p10 %.2f p50 %.2f p90 %.2f max %.2f us\n", sm / G, sw / G * 0.01, sm / sw * 100.0,
+           life[G / 10], life[G / 2], life[G * 9 / 10], life[G - 1]);
+    for (int ph = 0; ph < 7; ++ph) { double mx = 0; for (int b = 0; b < G; ++b) for (int w = 0; w < 16; ++w) mx = std::max(mx, (double)h[(size_t)b * 128 + w * 8 + ph]); printf("phase %d max over waves %9.0f\n", ph, mx); }
   }
   return 0;
 }

@@ -887,12 +887,17 @@ __device__ __forceinline__ void vqs_score_group(const bf16x8* __restrict__ wl, c
       f32x4 acc = mfma16(a0, z[t].f[0], en4);
       acc = mfma16(a1, z[t].f[1], acc);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        // (written in C, not as inline assembly: the first reader of a matrix-core result must be an instruction the compiler sees,
-        // or the wait states between v_mfma and the read are not inserted)
-        const unsigned key = (__float_as_uint(acc[r]) & maskv) | (unsigned)(4 * j + r);
-        asm("v_med3_f32 %0, %1, %2, %3" : "=v"(c2[t]) : "v"(c1[t]), "v"(c2[t]), "v"(key));   // runner-up (c1 <= c2)
-        asm("v_min_f32 %0, %1, %2" : "=v"(c1[t]) : "v"(c1[t]), "v"(key));
+      for (int r = 0; r < 4; r += 2) {
+        // (the keys are made in C, not in the inline assembly: the first reader of a matrix-core result must be an instruction the
+        // compiler sees, or the wait states between v_mfma and the read are not inserted)
+        const unsigned k0 = (__float_as_uint(acc[r]) & maskv) | (unsigned)(4 * j + r);
+        const unsigned k1 = (__float_as_uint(acc[r + 1]) & maskv) | (unsigned)(4 * j + r + 1);
+        // two keys per update, 2.5 vector operations per score: with c1 <= c2 the second smallest of {c1, c2, k0, k1} is
+        // min(c2, median(c1, k0, k1)); then c1 = min3(c1, k0, k1)
+        unsigned m;
+        asm("v_med3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(c1[t]), "v"(k0), "v"(k1));
+        asm("v_min_f32 %0, %1, %2" : "=v"(c2[t]) : "v"(c2[t]), "v"(m));
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(c1[t]) : "v"(c1[t]), "v"(k0), "v"(k1));
       }
     }
   };
@@ -964,6 +969,13 @@ __device__ __forceinline__ int vqs_resolve_inlane(const LQTile<bf16, 2>& zt, con
 
 #define VQS_CAP 8            // ambiguous rows per wave whose vectors are kept in LDS for the joint pass behind the batch loop (16 * 8 = VQ_FAST_ROWS)
 #define VQS_CAND (VQS_NW * 64)
+// z_q / index stores of the batch loop: non-temporal (streamed past the L2), so that the output drains to HBM while later batches are
+// scored instead of sitting dirty in the L2 until the release fence of the arrival ticket / the end-of-kernel write-back
+#ifndef VQS_PLAIN_STORES
+#define VQS_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define VQS_STORE(p, v) (*(p) = (v))
+#endif
 template <int NT>
 __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
     const bf16* __restrict__ Z, const float* __restrict__ en_g, int64_t N, int K, int Kc, int32_t* __restrict__ idx_out,
@@ -990,6 +1002,13 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
   const int vx = lane & 15, kc = lane >> 4;
   const int nmb = Kc / 16;
   const int64_t nbatch = N / BATCH;                                // (the host checks N % BATCH == 0 and launches at most nbatch workgroups)
+#ifdef VQ_STAMPS
+  __shared__ unsigned long long vq_ts[16][8];                       // (the VQ_ST macro of the resident kernel: phase durations per wave)
+  if (tid < 128) (&vq_ts[0][0])[tid] = 0ull;
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_begin = t_prev;
+  const unsigned long long w_begin = wall_clock64();
+#endif
   LQTile<bf16, NF> bufA[NT], bufB[NT];
   auto load_batch = [&](LQTile<bf16, NF> (&dst)[NT], int64_t b) {
     const int64_t r0 = b * BATCH + (int64_t)wave * (NT * 16);
@@ -998,14 +1017,20 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
   };
   load_batch(bufA, blockIdx.x);
   // ---- once per workgroup: codebook image, norms, their maximum, cleared histogram / lists ----
-  for (int i = tid; i < nmb * NF * 64; i += NW * 64) wl[i] = pk[i];
+  const float env = tid < K ? en_g[tid] : 3.0e38f;                 // (requested before the image so that both arrive in one round trip)
+  for (int i0 = 0; i0 < nmb * NF * 64; i0 += 4 * NW * 64) {        // four 16-byte loads in flight per thread (64 KB per pass of the workgroup)
+    bf16x8 tmp[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = i0 + u * NW * 64 + tid; if (i < nmb * NF * 64) tmp[u] = pk[i]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = i0 + u * NW * 64 + tid; if (i < nmb * NF * 64) wl[i] = tmp[u]; }
+  }
   float enmax;
   {
     float m = 0.f;
-    for (int i = tid; i < Kc; i += NW * 64) {
-      const float v = i < K ? en_g[i] : 3.0e38f;
-      enl[i] = v;
-      if (i < K) m = fmaxf(m, v);
+    if (tid < Kc) {                                                  // (Kc <= VQ_MAX_CHUNK <= threads: one norm per thread, loaded above)
+      enl[tid] = env;
+      if (tid < K) m = env;
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
@@ -1027,6 +1052,7 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
   float sq_acc = 0.f;
   int n_resolved = 0, cnt_w = 0;                                   // (wave-uniform) rows re-evaluated / rows parked in this wave's LDS segment
   bf16* zp = zpark + wave * 16 * VQS_ZP;
+  VQ_ST(2);                                                        // image, norms, lists
 
   // one batch: `cur` holds its rows (requested one batch earlier), `nxt` receives the rows of the batch after it
   auto step = [&](LQTile<bf16, NF> (&cur)[NT], LQTile<bf16, NF> (&nxt)[NT], int64_t batch) {
@@ -1034,6 +1060,7 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
     // the rows of this batch were requested a whole batch ago; behind them only the 3 * NT stores of the previous batch were issued
     // (every vector-memory operation of a step is issued unconditionally; the last step requests its own rows again: an L2 hit)
     vqs_wait<NT, 3 * NT>(cur);
+    VQ_ST(0);                                                      // waiting for this batch's rows
     load_batch(nxt, batch + (int64_t)gridDim.x < nbatch ? batch + gridDim.x : batch);
     float thr[NT];
     unsigned g1[NT], g2[NT];
@@ -1065,6 +1092,7 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
         if (b1 < a1) { g1[t] = c1[t]; gc[t] = g0; }
       }
     }
+    VQ_ST(3);                                                      // norms + scoring
     // ---- min-reduce over the 4 lane groups that share a row (code = block * 16 + 4 * quarter + accumulator row, the quarter is the
     // lane's own); ambiguity test; z_q, squared error, histogram ----
 #pragma unroll
@@ -1124,15 +1152,16 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
             const float df = (float)cur[t].f[s][e] - f;
             sl = fmaf(df, df, sl);
           }
-          *reinterpret_cast<bf16x8*>(zo + 8 * s) = ev;
+          VQS_STORE(reinterpret_cast<bf16x8*>(zo + 8 * s), ev);
         }
-        idx_out[row] = code;                                       // (the four lanes of a row store the same word)
+        VQS_STORE(idx_out + row, code);                            // (the four lanes of a row store the same word)
         if (!parked) {
           sq_acc += sl;
           if (kc == 0) atomicAdd(&hist[code], 1);
         }
       }
     }
+    VQ_ST(4);                                                      // reduce, ambiguity test, z_q, histogram
   };
   for (int64_t batch = blockIdx.x; batch < nbatch; batch += 2 * (int64_t)gridDim.x) {
     step(bufA, bufB, batch);
@@ -1143,6 +1172,7 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
   // the parked rows before the final ones below.
   vqs_wait<NT, 0>(bufA);
   vqs_wait<NT, 0>(bufB);
+  VQ_ST(1);                                                        // store drain behind the last batch
   // ---- the parked rows of the whole workgroup (<= 8 per wave, in (wave, slot) = row order): every wave re-scores them against its share
   // of the code blocks, one lane per candidate evaluates the float64 distance, LDS integer atomics keep the minimum and then the
   // smallest code among the minima -- the all-wave pass of the resident kernel ----
@@ -1237,6 +1267,7 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
       }
     }
   }
+  VQ_ST(5);                                                        // joint pass over the parked rows
   // ---- per-workgroup outputs: wave partials of the squared error; histogram by integer atomics (order-independent) ----
   const float ws_ = wave_sum(sq_acc);
   if (lane == 0) {
@@ -1292,6 +1323,12 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
       __hip_atomic_store(&ctl->done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+#ifdef VQ_STAMPS
+  VQ_ST(6);                                                        // partials, histogram atomics, ticket, (last workgroup) statistics
+  __syncthreads();
+  if (tid < 128) vq_dbg[(size_t)blockIdx.x * 128 + tid] = (&vq_ts[0][0])[tid];
+  if (tid == 0) { vq_dbg[(size_t)gridDim.x * 128 + 2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_begin; vq_dbg[(size_t)gridDim.x * 128 + 2 * blockIdx.x + 1] = wall_clock64() - w_begin; }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
