@@ -228,6 +228,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void vq_assign_kernel(
       for (int s = 0; s < NF; ++s) asm volatile("" : "+v"(zt[t].f[s]));   // (else the unpacked floats stay live through the chunk loop)
       g1[t] = 0x7F800000u; g2[t] = 0x7F800000u; gc[t] = 0;         // +inf
     }
+    unsigned maskv = ~VQ_IDX_MASK;
+    asm volatile("" : "+v"(maskv));                                // (opaque and in a register: (score & mask) | index then selects as ONE v_and_or_b32)
     for (int c = 0; c < nchunks; ++c, ++it) {
       const int buf = (int)(it & 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of chunk `it` (and its norm loads) have landed
@@ -246,17 +248,23 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void vq_assign_kernel(
           frag_t a[NF];
 #pragma unroll
           for (int s = 0; s < NF; ++s) a[s] = wl[(mb * NF + s) * 64 + lane];
-          const unsigned lidx = (unsigned)((mb - g0) * 16 + 4 * kc);
+          const unsigned lidx = (unsigned)((mb - g0) * 4);            // (wave-uniform)
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             f32x4 acc = en4;
 #pragma unroll
             for (int s = 0; s < NF; ++s) acc = mfma16(a[s], zt[t].f[s], acc);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const unsigned key = (__float_as_uint(acc[r]) & ~VQ_IDX_MASK) | (lidx + r);
-              asm("v_med3_f32 %0, %1, %2, %3" : "=v"(c2[t]) : "v"(c1[t]), "v"(c2[t]), "v"(key));   // runner-up (c1 <= c2)
-              asm("v_min_f32 %0, %1, %2" : "=v"(c1[t]) : "v"(c1[t]), "v"(key));
+            for (int r = 0; r < 4; r += 2) {
+              // key index = (block in group) * 4 + accumulator row (the lane adds its quarter when it decodes); two keys per update:
+              // with c1 <= c2 the second smallest of {c1, c2, k0, k1} is min(c2, median(c1, k0, k1)); 2.5 vector operations per score
+              unsigned i0 = lidx + r, i1 = lidx + r + 1;
+              asm("" : "+s"(i0), "+s"(i1));                            // (opaque scalars: else the odd index becomes v_and + v_or3)
+              const unsigned k0 = (__float_as_uint(acc[r]) & maskv) | i0, k1 = (__float_as_uint(acc[r + 1]) & maskv) | i1;
+              unsigned m;
+              asm("v_med3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(c1[t]), "v"(k0), "v"(k1));
+              asm("v_min_f32 %0, %1, %2" : "=v"(c2[t]) : "v"(c2[t]), "v"(m));
+              asm("v_min3_f32 %0, %1, %2, %3" : "=v"(c1[t]) : "v"(c1[t]), "v"(k0), "v"(k1));
             }
           }
         }
@@ -273,17 +281,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void vq_assign_kernel(
     // ---- min-reduce over the 4 lane groups that share a row; ambiguity test; z_q, squared error, histogram of the settled rows ----
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+      int cd1 = (gc[t] + (int)((g1[t] & VQ_IDX_MASK) >> 2)) * 16 + 4 * kc + (int)(g1[t] & 3u);   // the lane's own best code
 #pragma unroll
       for (int off = 16; off <= 32; off <<= 1) {
         const unsigned o1 = __shfl_xor(g1[t], off, 64), o2 = __shfl_xor(g2[t], off, 64);
-        const int oc = __shfl_xor(gc[t], off, 64);
-        const float a1 = __uint_as_float(g1[t]), a2 = __uint_as_float(g2[t]), b1 = __uint_as_float(o1), b2 = __uint_as_float(o2);
-        const float hi = fmaxf(a1, b1), lo2 = fminf(a2, b2);
+        const int oc = __shfl_xor(cd1, off, 64);
+        const float a1 = __uint_as_float(g1[t] & ~VQ_IDX_MASK), a2 = __uint_as_float(g2[t]), b1 = __uint_as_float(o1 & ~VQ_IDX_MASK), b2 = __uint_as_float(o2);
+        const float hi = fmaxf(__uint_as_float(g1[t]), __uint_as_float(o1)), lo2 = fminf(a2, b2);
         g2[t] = __float_as_uint(fminf(hi, lo2));
-        if (b1 < a1 || (b1 == a1 && (oc < gc[t] || (oc == gc[t] && o1 < g1[t])))) { g1[t] = o1; gc[t] = oc; }
+        if (b1 < a1 || (b1 == a1 && oc < cd1)) { g1[t] = o1; cd1 = oc; }
       }
       const int64_t row = v0 + t * 16 + vx;
-      const int code = gc[t] * 16 + (int)(g1[t] & VQ_IDX_MASK);
+      const int code = cd1;
       const float s1 = __uint_as_float(g1[t] & ~VQ_IDX_MASK), s2 = __uint_as_float(g2[t] & ~VQ_IDX_MASK);
       const bool amb = !((s2 - s1) > thr[t]) || (unsigned)code >= (unsigned)K;   // also catches NaN / inf rows
       if (row < N) {
