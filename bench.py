@@ -200,6 +200,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
+        if world > 1:
+            import time
+            time.sleep(3.0)        # the launcher ends the other ranks as soon as one fails: let every rank reach this line and say so
         raise SystemExit("bench.py needs an MI355X: the hot path is HIP-only (no CPU fallback)")
     local_rank %= max(torch.cuda.device_count(), 1)      # (identity on an N-GPU node; lets a 1-GPU box rehearse N ranks with gloo)
     torch.cuda.set_device(local_rank)

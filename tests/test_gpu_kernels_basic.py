@@ -148,7 +148,9 @@ def test_vq_assign_every_row_is_a_tie(dtype, N, K, d, dup):
 
 
 @pytest.mark.parametrize("N,K,case", [(4096, 512, "randn"), (2048, 256, "ties"), (1024, 200, "randn"), (256, 16, "ties"), (1536, 512, "dup2"),
-                                      (512, 64, "dup64"), (262144, 512, "live"), (8192, 512, "nan")])
+                                      (512, 64, "dup64"), (262144, 512, "live"), (8192, 512, "nan"),
+                                      # uneven hand-out: 300 batches on 256 workgroups (one or two per workgroup), 768 batches (three: an odd count)
+                                      (76800, 512, "randn"), (196608, 256, "ties")])
 def test_vq_assign_streaming_kernel_matches_resident(N, K, case):
     """The streaming assignment kernel (one 16-wave workgroup per CU, wave-local exact re-evaluation; bf16 rows of 64 channels, whole
     batches) against the float64 arg-min and against the resident kernel of round 2: indices, z_q, histogram and the number of rows
