@@ -989,7 +989,7 @@ template <int NT>
 __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
     const bf16* __restrict__ Z, const float* __restrict__ en_g, int64_t N, int K, int Kc, int32_t* __restrict__ idx_out,
     bf16* __restrict__ zq_out, float* __restrict__ partial /*[grid*NW]*/, const bf16x8* __restrict__ pk, VqCtl* __restrict__ ctl,
-    int32_t* __restrict__ counts_out, float* __restrict__ stats_out) {
+    int32_t* __restrict__ counts_out, float* __restrict__ stats_out, unsigned* __restrict__ ovf_row /*[N]*/, float* __restrict__ ovf_lim /*[N]*/) {
   constexpr int NF = 2, q = 16, d = 64, NW = VQS_NW;
   constexpr int BATCH = NW * NT * 16;
   static_assert(NW * VQS_CAP <= VQ_FAST_ROWS, "parked rows of a workgroup");
@@ -1059,8 +1059,14 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
   const float thr_rel = (3.0517578125e-5f + 2.f * err_rel) * 1.001953125f;   // 2^-15: key truncation of both scores, + 2*err, + margin
   const float enroot = sqrtf(enmax);
   float sq_acc = 0.f;
-  int n_resolved = 0, cnt_w = 0;                                   // (wave-uniform) rows re-evaluated / rows parked in this wave's LDS segment
+  int n_resolved = 0, cnt_w = 0, ovf_cnt = 0;                      // (wave-uniform) rows re-evaluated / parked in the wave's LDS segment / in its overflow list
+  // overflow list of the wave (rows that found the LDS segment full; constructed inputs only): entry k lives in the slot of the wave's k-th
+  // row, so a wave touches nothing but the slots of its own rows and the list needs no room beyond the N entries of the workspace
+  auto ovf_slot = [&](int k) -> int64_t {
+    return ((int64_t)blockIdx.x + (int64_t)(k / (NT * 16)) * gridDim.x) * BATCH + (int64_t)wave * (NT * 16) + (k % (NT * 16));
+  };
   bf16* zp = zpark + wave * 16 * VQS_ZP;
+  int nstep = 0;                                                   // (wave-uniform) batches behind this wave
   VQ_ST(2);                                                        // image, norms, lists
 
   // one batch: `cur` holds its rows (requested one batch earlier), `nxt` receives the rows of the batch after it
@@ -1068,6 +1074,10 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
     const int64_t v0 = batch * BATCH + (int64_t)wave * (NT * 16);
     // the rows of this batch were requested a whole batch ago; behind them only the 3 * NT stores of the previous batch were issued
     // (every vector-memory operation of a step is issued unconditionally; the last step requests its own rows again: an L2 hit)
+    // issue priority falls with the batches a wave has behind it: the arbiter otherwise favours the oldest wave of a SIMD throughout, the
+    // four waves finish a quarter of the loop apart and the last one runs alone, unable to hide its own MFMA / LDS latencies
+    { if (nstep == 0) __builtin_amdgcn_s_setprio(3); else if (nstep == 1) __builtin_amdgcn_s_setprio(2); else if (nstep == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+    ++nstep;
     vqs_wait<NT, 3 * NT>(cur);
     VQ_ST(0);                                                      // waiting for this batch's rows
     load_batch(nxt, batch + (int64_t)gridDim.x < nbatch ? batch + gridDim.x : batch);
@@ -1125,7 +1135,8 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
       bool parked = false;
       if (pm != 0ull) {                                            // (wave-uniform) this tile holds rows to re-evaluate exactly
         const int np = __builtin_popcountll(pm);
-        if (cnt_w + np <= VQS_CAP) {
+        const bool fits = cnt_w + np <= VQS_CAP;                   // (wave-uniform)
+        if (fits) {
           // the usual case (0.3-0.7 % of the rows): vector, row and limit go to the wave's LDS segment in row order, the whole workgroup
           // resolves them behind the batch loop; the provisional z_q / index below are stored all the same (the store count per
           // step stays fixed) and overwritten there
@@ -1135,16 +1146,19 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
             *reinterpret_cast<bf16x8*>(zdef + e * VQS_ZP + q * kc + 8) = cur[t].f[1];
             if (kc == 0) { prow[e] = (unsigned)row; plim[e] = lm; }
           }
-          cnt_w += np;
-          parked = amb;
         } else {
-          // segment full (constructed inputs: every row a tie): the wave resolves the tile on its own, no other wave is waited for
-          *reinterpret_cast<bf16x8*>(zp + vx * VQS_ZP + q * kc) = cur[t].f[0];
-          *reinterpret_cast<bf16x8*>(zp + vx * VQS_ZP + q * kc + 8) = cur[t].f[1];
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private scratch: LDS operations of one wave complete in order
-          const int bk = vqs_resolve_inlane(cur[t], zp + vx * VQS_ZP, wl, enl, nmb, K, lane, kc, amb, lm);
-          if (amb) code = bk;
+          // segment full (constructed inputs: every row a tie): row and limit go to the wave's overflow list in global memory and the wave
+          // resolves them on its own behind the loop (the float64 path stays out of the loop's register budget; the two extra stores only
+          // add to the vector-memory operations issued behind the pending row loads, which the wait above tolerates)
+          if (amb && kc == 0) {
+            const int64_t sl_ = ovf_slot(ovf_cnt + __builtin_popcountll(pm & ((1ull << vx) - 1ull)));
+            ovf_row[sl_] = (unsigned)row;
+            ovf_lim[sl_] = lm;
+          }
         }
+        cnt_w += fits ? np : 0;                                    // (plain arithmetic on both counters: a store through a selected
+        ovf_cnt += fits ? 0 : np;                                  //  address would move them to scratch memory)
+        parked = amb;
         n_resolved += np;
       }
       {
@@ -1179,6 +1193,7 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
   // the last step's (redundant) row loads are still in flight and the compiler does not know it: both buffers stay live up to this wait,
   // so their registers cannot be handed to the tail's variables before the loads have landed.  It also orders the provisional stores of
   // the parked rows before the final ones below.
+  __builtin_amdgcn_s_setprio(0);
   vqs_wait<NT, 0>(bufA);
   vqs_wait<NT, 0>(bufB);
   VQ_ST(1);                                                        // store drain behind the last batch
@@ -1276,7 +1291,41 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
       }
     }
   }
-  VQ_ST(5);                                                        // joint pass over the parked rows
+  // ---- the wave's overflow list, 16 rows at a time: vectors back from global memory (and into the wave's LDS scratch for the float64
+  // distances), the tile re-scored against the whole image, candidates evaluated in-lane ----
+  for (int t0 = 0; t0 < ovf_cnt; t0 += 16) {                        // (wave-uniform trip count)
+    const int kq = t0 + vx;
+    const bool valid = kq < ovf_cnt;
+    const int64_t sl_ = ovf_slot(valid ? kq : t0);
+    const int64_t row = (int64_t)__hip_atomic_load(&ovf_row[sl_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (written by this wave; past the L1)
+    const float lm = __hip_atomic_load(&ovf_lim[sl_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    LQTile<bf16, NF> zr;
+    zr.f[0] = *reinterpret_cast<const bf16x8*>(Z + row * d + q * kc);
+    zr.f[1] = *reinterpret_cast<const bf16x8*>(Z + row * d + q * kc + 8);
+    *reinterpret_cast<bf16x8*>(zp + vx * VQS_ZP + q * kc) = zr.f[0];
+    *reinterpret_cast<bf16x8*>(zp + vx * VQS_ZP + q * kc + 8) = zr.f[1];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // wave-private scratch: LDS operations of one wave complete in order
+    const int bk = vqs_resolve_inlane(zr, zp + vx * VQS_ZP, wl, enl, nmb, K, lane, kc, valid, lm);
+    if (valid) {
+      bf16* zo = zq_out + row * (int64_t)d + q * kc;
+#pragma unroll
+      for (int s = 0; s < NF; ++s) {
+        const bf16x8 pv = wl[((bk >> 4) * NF + s) * 64 + (bk & 15) + 16 * kc];
+        bf16x8 ev;
+#pragma unroll
+        for (int e2 = 0; e2 < 8; ++e2) {
+          const float f = -0.5f * (float)pv[e2];
+          ev[e2] = (bf16)f;
+          const float df = (float)zr.f[s][e2] - f;
+          sq_acc = fmaf(df, df, sq_acc);
+        }
+        *reinterpret_cast<bf16x8*>(zo + 8 * s) = ev;
+      }
+      if (kc == 0) { idx_out[row] = bk; atomicAdd(&hist[bk], 1); }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (the scratch is rewritten by the next tile)
+  }
+  VQ_ST(5);                                                        // joint pass over the parked rows, overflow list
   // ---- per-workgroup outputs: wave partials of the squared error; histogram by integer atomics (order-independent) ----
   const float ws_ = wave_sum(sq_acc);
   if (lane == 0) {
@@ -1823,7 +1872,7 @@ static int launch_vq_prepare(const float* E, int64_t N, int K, int d, char* prep
 static int g_vq_stream_tiles = -1;    // frl_vq_stream_tiles(): -1 = the FRL_VQ_STREAM environment variable, else VQ_STREAM_DEFAULT
 static int vq_stream_tiles();
 #ifndef VQ_STREAM_DEFAULT
-#define VQ_STREAM_DEFAULT 1   // tiles per wave and batch of the streaming kernel when FRL_VQ_STREAM is unset (0: resident kernel)
+#define VQ_STREAM_DEFAULT 2   // tiles per wave and batch of the streaming kernel when FRL_VQ_STREAM is unset (0: resident kernel)
 #endif
 static int vq_stream_tiles() {
   if (g_vq_stream_tiles >= 0) return g_vq_stream_tiles;
@@ -1855,7 +1904,8 @@ static int launch_vq(const void* z, const float* E, char* prep, int64_t N, int K
     // streaming form (one 16-wave workgroup per CU, no workgroup barrier in the batch loop); FRL_VQ_STREAM=0 selects the older kernel,
     // FRL_VQ_STREAM=1 / 2 / 4 the 16-row tiles per wave and batch (A/B hook, read once)
     const int stream_nt = vq_stream_tiles();
-    const int nt = stream_nt >= 4 ? 4 : (stream_nt >= 2 ? 2 : 1);
+    int nt = stream_nt >= 4 ? 4 : (stream_nt >= 2 ? 2 : 1);
+    while (nt > 1 && N % (VQS_NW * nt * 16) != 0) nt >>= 1;          // whole batches only: fewer tiles per wave when the row count asks for it
     const int batch = VQS_NW * nt * 16;
     if (resident && stream_nt > 0 && d == 64 && (Kc & 15) == 0 && N % batch == 0 && N < ((int64_t)1 << 32)) {   // whole batches only: no row guards in the kernel
       const int64_t nb = (N + batch - 1) / batch;
@@ -1869,7 +1919,8 @@ static int launch_vq(const void* z, const float* E, char* prep, int64_t N, int K
     auto kern = vq_assign_stream_kernel<NT_>;                                                                                      \
     if (lds > 64 * 1024) FRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
     FRL_LAUNCH_AS("vq_assign_kernel", kern, dim3(grid_s), dim3(64 * VQS_NW), lds, st, (const bf16*)z, en, N, K, Kc, idx, (bf16*)zq,  \
-                  (float*)(ws + L.partial), (const bf16x8*)pk, (VqCtl*)(prep + P.ctl), counts, stats);                              \
+                  (float*)(ws + L.partial), (const bf16x8*)pk, (VqCtl*)(prep + P.ctl), counts, stats, (unsigned*)(ws + L.amb),      \
+                  (float*)(ws + L.amb_lim));                                                                                       \
   } while (0)
       if (nt == 4) VQ_GOS(4); else if (nt == 2) VQ_GOS(2); else VQ_GOS(1);
 #undef VQ_GOS
