@@ -888,9 +888,14 @@ template <int NT, bool FULL>
 __device__ __forceinline__ void vqs_score_group(const bf16x8* __restrict__ wl, const float* __restrict__ enl, int lane, int kc, int mb0, int cnt,
                                                 const LQTile<bf16, 2> (&z)[NT], unsigned (&c1)[NT], unsigned (&c2)[NT]) {
   const unsigned maskv = ~VQ_IDX_MASK;
+  // (one base per group + constant element offsets: the block's three LDS reads then carry immediate offsets instead of an address
+  // computation each)
+  const bf16x8* __restrict__ wb = wl + mb0 * 2 * 64 + lane;
+  const float* __restrict__ eb = enl + mb0 * 16 + 4 * kc;
   auto block = [&](int mb, int j) {
-    const f32x4 en4 = *reinterpret_cast<const f32x4*>(enl + mb * 16 + 4 * kc);
-    const bf16x8 a0 = wl[(mb * 2 + 0) * 64 + lane], a1 = wl[(mb * 2 + 1) * 64 + lane];
+    (void)mb;
+    const f32x4 en4 = *reinterpret_cast<const f32x4*>(eb + j * 16);
+    const bf16x8 a0 = wb[j * 2 * 64], a1 = wb[j * 2 * 64 + 64];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       f32x4 acc = mfma16(a0, z[t].f[0], en4);
