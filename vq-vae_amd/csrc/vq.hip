@@ -1334,7 +1334,8 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
   // ---- per-workgroup outputs: wave partials of the squared error; histogram by integer atomics (order-independent) ----
   const float ws_ = wave_sum(sq_acc);
   if (lane == 0) {
-    partial[blockIdx.x * NW + wave] = ws_;
+    // (device-scope store: written through, so the arrival ticket below needs no L2 write-back in front of it)
+    __hip_atomic_store(&partial[blockIdx.x * NW + wave], ws_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (n_resolved) atomicAdd(&misc[0], n_resolved);
   }
   __syncthreads();
@@ -1343,12 +1344,13 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
     if (h) atomicAdd(&counts_acc[k], h);
   }
   if (tid == 0 && misc[0]) atomicAdd(&ctl->namb, misc[0]);
-  // publish (partials by plain stores, counts by atomics), then take a ticket; the last workgroup folds everything
+  // publish, then take a ticket; the last workgroup folds everything.  What the last workgroup reads -- the partials and the histogram
+  // accumulator -- was written by device-scope stores / atomics and every wave has waited for their completion in front of the barrier,
+  // so the ticket is not preceded by a release fence (an L2 write-back of all the z_q lines the XCD still holds: one more device-scope
+  // round trip on the tail of every workgroup); the outputs themselves become visible at the end of the kernel as always
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int ticket = __hip_atomic_fetch_add(&ctl->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     misc[17] = (ticket == (int)gridDim.x - 1) ? 1 : 0;
     if (ticket == (int)gridDim.x - 1) {
