@@ -983,9 +983,10 @@ __device__ __forceinline__ int vqs_resolve_inlane(const LQTile<bf16, 2>& zt, con
 
 #define VQS_CAP 8            // ambiguous rows per wave whose vectors are kept in LDS for the joint pass behind the batch loop (16 * 8 = VQ_FAST_ROWS)
 #define VQS_CAND (VQS_NW * 64)
-// z_q / index stores of the batch loop: non-temporal (streamed past the L2), so that the output drains to HBM while later batches are
-// scored instead of sitting dirty in the L2 until the release fence of the arrival ticket / the end-of-kernel write-back
-#ifndef VQS_PLAIN_STORES
+// z_q / index stores of the batch loop.  Plain stores: the two 64-byte halves of a row's line come from two instructions and are merged
+// in the L2.  Non-temporal stores (-DVQS_NT_STORES) drain while later batches are scored and were 0.7 us faster (44.6 against 45.3 us),
+// but each half then travels to HBM on its own: WRITE_SIZE 60.4 MB per launch against 41.7 MB (algorithmic 34.6 MB) -- not kept.
+#ifdef VQS_NT_STORES
 #define VQS_STORE(p, v) __builtin_nontemporal_store((v), (p))
 #else
 #define VQS_STORE(p, v) (*(p) = (v))
@@ -1024,10 +1025,10 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
   const unsigned long long w_begin = wall_clock64();
 #endif
   LQTile<bf16, NF> bufA[NT], bufB[NT];
-  auto load_batch = [&](LQTile<bf16, NF> (&dst)[NT], int64_t b) {
+  auto load_batch = [&](LQTile<bf16, NF> (&dst)[NT], int64_t b, bool real = true) {
     const int64_t r0 = b * BATCH + (int64_t)wave * (NT * 16);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) vqs_load_row(dst[t], Z + (r0 + t * 16 + vx) * d + q * kc);
+    for (int t = 0; t < NT; ++t) vqs_load_row(dst[t], Z + (r0 + (real ? t * 16 + vx : 0)) * d + q * kc);   // (!real: one cached line, see step)
   };
   load_batch(bufA, blockIdx.x);
   // ---- once per workgroup: codebook image, norms, their maximum, cleared histogram / lists ----
@@ -1078,14 +1079,15 @@ __global__ __launch_bounds__(VQS_NW * 64, 1) void vq_assign_stream_kernel(
   auto step = [&](LQTile<bf16, NF> (&cur)[NT], LQTile<bf16, NF> (&nxt)[NT], int64_t batch) {
     const int64_t v0 = batch * BATCH + (int64_t)wave * (NT * 16);
     // the rows of this batch were requested a whole batch ago; behind them only the 3 * NT stores of the previous batch were issued
-    // (every vector-memory operation of a step is issued unconditionally; the last step requests its own rows again: an L2 hit)
+    // (every vector-memory operation of a step is issued unconditionally; the last step requests one line of its own rows again, a cache hit)
     // issue priority falls with the batches a wave has behind it: the arbiter otherwise favours the oldest wave of a SIMD throughout, the
     // four waves finish a quarter of the loop apart and the last one runs alone, unable to hide its own MFMA / LDS latencies
     { if (nstep == 0) __builtin_amdgcn_s_setprio(3); else if (nstep == 1) __builtin_amdgcn_s_setprio(2); else if (nstep == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     ++nstep;
     vqs_wait<NT, 3 * NT>(cur);
     VQ_ST(0);                                                      // waiting for this batch's rows
-    load_batch(nxt, batch + (int64_t)gridDim.x < nbatch ? batch + gridDim.x : batch);
+    const bool has_next = batch + (int64_t)gridDim.x < nbatch;
+    load_batch(nxt, has_next ? batch + gridDim.x : batch, has_next);
     float thr[NT];
     unsigned g1[NT], g2[NT];
     int gc[NT];
